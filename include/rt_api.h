@@ -1,0 +1,210 @@
+/*
+ * rt_api.h — C-ABI of the MI355X path-tracing backend (librtiow_hip.so).
+ *
+ * This is the drop-in boundary.  The reference has no plugin API; the seam this
+ * library replaces is the worker pool of RaytracerState::new
+ * (raytracer/src/main.rs:1326-1409): per pixel `Camera::raytrace_pixel`
+ * (raytracer/src/camera.rs:186-251), the gamma/validity pass (main.rs:1363-1388)
+ * and the store into `image_pixels[y*W+x]` (main.rs:1461-1466).  Inputs are the same
+ * things that loop reads: RaytracerParams (main.rs:1157-1176), the camera
+ * (camera.rs:25-36), `world`, `lights` and the sampler table (sampling.rs:11-24) —
+ * here flattened by the host into the plain arrays below.
+ *
+ * Conventions: every function returns rt_status (0 = OK, negative = error) and
+ * never throws or aborts; rt_last_error() gives the text.  All pointers in the
+ * *_desc structs are HOST pointers owned by the caller for the duration of the
+ * call only — the library copies what it keeps.  A context drives one GPU from one
+ * host thread at a time.  Image buffers are row-major, row 0 = top, 4 x f32 per
+ * pixel (math/src/colors.rs:53-63).
+ */
+#ifndef RT_API_H
+#define RT_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+typedef enum rt_status {
+    RT_OK                      =  0,
+    RT_E_INVALID               = -1,  /* bad argument / inconsistent descriptor        */
+    RT_E_HIP                   = -2,  /* a HIP runtime call failed                      */
+    RT_E_RCCL                  = -3,  /* reserved (collectives live in the host layer)  */
+    RT_E_OOM                   = -4,  /* device allocation failed                       */
+    RT_E_UNSUPPORTED_PRIMITIVE = -5,  /* scene uses something the kernels do not cover  */
+    RT_E_NO_DEVICE             = -6,  /* no usable GPU                                  */
+    RT_E_CANCELLED             = -7   /* *cancel became non-zero between batches        */
+} rt_status;
+
+/* ---------------------------------------------------------------- flattened scene */
+
+/* Primitive slot type (word 4, bits 0-3 of a slot). */
+enum rt_prim_type {
+    RT_PRIM_SPHERE        = 0,
+    RT_PRIM_MOVING_SPHERE = 1,
+    RT_PRIM_XY_RECT       = 2,
+    RT_PRIM_XZ_RECT       = 3,
+    RT_PRIM_YZ_RECT       = 4,
+    RT_PRIM_TRIANGLE      = 5
+};
+
+#define RT_SLOT_FLOATS   16   /* one primitive slot = 64 B                        */
+#define RT_NODE_FLOATS   16   /* one BVH node       = 64 B                        */
+#define RT_ATTR_FLOATS   16   /* triangle shading attributes = 64 B               */
+#define RT_REC_FLOATS     8   /* material / texture / xform / medium / light rec  */
+#define RT_PERLIN_WORDS 1536  /* 256*3 f32 gradient + 3*256 i32 permutations      */
+#define RT_BVH_EMPTY  0x7fffffff
+#define RT_MISS       0xffffffffu
+
+/*
+ * Layouts (all little-endian 32-bit words; "i:" = int32 bit pattern in a float lane)
+ *
+ * BVH node  [0..5] left child box min.xyz max.xyz   [6..11] right child box
+ *           [12] i: left ref  [13] i: right ref  [14..15] 0
+ *           ref >= 0: inner node index;  ref < 0: leaf, ~ref = first_slot<<3 | (count-1)
+ *
+ * slot      [0..3]  q0 geometry   [4] i: type | flip<<4 | (xform+1)<<8
+ *           (flip = FlipFace parity that survives Translate's HitRecord::new, transform.rs:36-44)
+ *           [5] i: material  [6] i: primitive id (rt_scene_graph.h numbering)
+ *           [7] type scalar  [8..11] q2 geometry  [12..15] 0
+ *   sphere         q0 = cx cy cz r
+ *   moving sphere  q0 = c0x c0y c0z r   [7] = time0   q2 = c1x c1y c1z time1
+ *   rects          q0 = a0 a1 b0 b1     [7] = k         (XY: a=x b=y, XZ: a=x b=z, YZ: a=y b=z)
+ *   triangle       q0 = p1x p1y p1z p2x [7] = p3z  q2 = p2y p2z p3x p3y
+ * tri attr  n1.xyz n2.xyz n3.xyz uv1.xy uv2.xy uv3.xy 0        (indexed by slot)
+ * xform     [0] i: bit0 rotate-y, bit1 translate  [1] sin [2] cos [3..5] offset
+ *           meaning Translate(RotateY(obj)) (transform.rs:9-153)
+ * medium    [0..3] boundary sphere c,r  [4] neg_inv_density  [5] i: material  [6] i: prim id
+ * light     [0] i: rt_prim_type (sphere or rect)  [1..5] q0 (+k for rects);  type 255 = an object that
+ *           keeps the trait defaults of hittable.rs:47-53 (pdf_value 0, random = unit_x)
+ * material  [0] i: rtg_material_type [1] i: texture [2..4] colour [5] fuzz [6] ior
+ * texture   [0] i: rtg_texture_type [1..3] colour [4] i: odd | perlin | texel offset
+ *           [5] i: even | width  [6] repeat | scale  [7] i: height
+ */
+typedef struct rt_scene_desc {
+    uint32_t struct_size;           /* sizeof(rt_scene_desc), for versioning */
+    const float   *bvh_nodes;       uint32_t n_bvh_nodes;
+    int32_t        bvh_root_ref;    /* RT_BVH_EMPTY when nothing is in the BVH */
+    uint32_t       bvh_stack_depth; /* entries a traversal stack needs (host computes it) */
+    const float   *slots;           uint32_t n_slots;
+    uint32_t       always_begin;    /* slots [always_begin, always_begin+always_count) are  */
+    uint32_t       always_count;    /* tested for every ray (top-level objects with no usable box) */
+    const float   *tri_attrs;       /* n_slots * RT_ATTR_FLOATS, or NULL if no triangles */
+    const float   *xforms;          uint32_t n_xforms;
+    const float   *media;           uint32_t n_media;    /* in world-list order */
+    const float   *lights;          uint32_t n_lights;   /* in lights-list order */
+    const float   *materials;       uint32_t n_materials;
+    const float   *textures;        uint32_t n_textures;
+    const uint32_t *perlin;         uint32_t n_perlin;   /* tables of RT_PERLIN_WORDS */
+    const uint8_t *texels;          uint64_t n_texel_bytes; /* RGBA8 atlas */
+    const uint32_t *moving_slots;   uint32_t n_moving_slots; /* slot indices of every MovingSphere: tested
+                                       directly when ray.time is outside the shutter interval the BVH boxes cover
+                                       (isotropic.rs:32 puts hit.t into ray.time) */
+    uint32_t       n_prims;         /* number of primitive ids in the scene */
+} rt_scene_desc;
+
+/* Sampler table: SamplerBase<MultiJittered> (raytracer/src/sampling.rs:11-24, 137-163). */
+typedef struct rt_sampler_desc {
+    uint32_t     sets;              /* 83 in the reference (sampling.rs:31) */
+    uint32_t     samples_in_set;    /* = samples_per_pixel */
+    const float *samples;           /* sets*samples_in_set * 2 : unit square */
+    const float *disk_samples;      /* sets*samples_in_set * 2 : unit disk   */
+    const uint32_t *shuffled_indices; /* sets*samples_in_set */
+} rt_sampler_desc;
+
+/* Camera block = the fields of `Camera` (raytracer/src/camera.rs:25-36). */
+typedef struct rt_camera {
+    float origin[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3], v[3], w[3];
+    float lens_radius;
+    float time0, time1;
+} rt_camera;
+
+enum rt_mem_location { RT_MEM_HOST = 0, RT_MEM_DEVICE = 1 };
+
+typedef struct rt_render_params {
+    uint32_t  struct_size;
+    int32_t   image_width, image_height;     /* full frame (main.rs:1160-1161)                 */
+    int32_t   samples_per_pixel;             /* spp of the whole frame = sampler samples_in_set */
+    int32_t   spp_begin, spp_count;          /* sample range rendered by THIS call             */
+    int32_t   max_ray_depth;                 /* main.rs:1164                                   */
+    float     background[3];                 /* main.rs:1172                                   */
+    uint32_t  seed;                          /* counter-RNG key; the reference is unseeded     */
+    int32_t   tile_x0, tile_y0, tile_x1, tile_y1; /* pixel rectangle, x1/y1 exclusive; 0,0,W,H = all */
+    rt_camera camera;
+    int32_t   out_location;                  /* rt_mem_location of out_rgba_sum                */
+    void     *stream;                        /* hipStream_t, NULL = default stream             */
+    const volatile int32_t *cancel;          /* polled between batches (main.rs:1338), may be NULL */
+    int32_t   collect_stats;                 /* 1 = run the counting variant and fill rt_stats */
+    uint32_t *pixel_rays;                    /* optional W*H counters (same location as the image): += rays
+                                                traced for that pixel; only with collect_stats = 1 */
+} rt_render_params;
+
+/* Work counters (SURVEY.md §8(d) FLOP model inputs).  Only filled when collect_stats=1. */
+typedef struct rt_stats {
+    uint64_t paths;            /* pixel samples started                                 */
+    uint64_t rays;             /* closest-hit queries issued by ray_color (camera.rs:264) */
+    uint64_t node_visits;      /* BVH nodes fetched                                     */
+    uint64_t box_tests;        /* child boxes tested (2 per node visit)                 */
+    uint64_t prim_tests[6];    /* by rt_prim_type, traversal + always-list              */
+    uint64_t medium_tests;     /* ConstantMedium::hit evaluations                       */
+    uint64_t light_pdf_evals;  /* lights.pdf_value object evaluations                   */
+    uint64_t shades[5];        /* scatter calls by rtg_material_type                    */
+    uint64_t tex_evals[4];     /* texture value() calls by rtg_texture_type             */
+    uint64_t accepted_hits;    /* rays that found a hit                                 */
+} rt_stats;
+
+/* ------------------------------------------------------------------- entry points */
+
+/* Number of HIP devices visible to this process (0 if none). */
+int rt_device_count(void);
+
+/* Create a context on one device.  Replaces the thread-pool set-up, main.rs:1314-1336. */
+int rt_create(int device_id, rt_ctx **out);
+void rt_destroy(rt_ctx *ctx);
+
+/* Text of the last error on this context (ctx may be NULL: last error of rt_create). */
+const char *rt_last_error(const rt_ctx *ctx);
+
+/* Copy the flattened `world` + `lights` to the device.
+ * Replaces `Arc::new(world)`, `Arc::new(lights)` handed to the workers, main.rs:1320-1333. */
+int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *scene);
+
+/* Copy the sampler table to the device.  Replaces `s.clone()` per worker, main.rs:1324,1335. */
+int rt_sampler_upload(rt_ctx *ctx, const rt_sampler_desc *sampler);
+
+/* Path-trace samples [spp_begin, spp_begin+spp_count) of every pixel of the tile and ADD the
+ * radiance sums into out_rgba_sum (W*H*4 f32, un-normalised; alpha += spp_count).
+ * Replaces the worker loop + Camera::raytrace_pixel, main.rs:1337-1361, camera.rs:186-309.
+ * With out_location = RT_MEM_DEVICE the call is asynchronous on params->stream. */
+int rt_render(rt_ctx *ctx, const rt_render_params *params, float *out_rgba_sum, rt_stats *stats);
+
+/* Gamma / validity pass, main.rs:1363-1388:  c = clamp(sqrt(sum/spp),0,1), !is_normal(sum) -> 0,
+ * alpha copied.  location applies to both pointers; stream as in rt_render (NULL = default). */
+int rt_resolve(rt_ctx *ctx, const float *rgba_sum, int32_t n_pixels, int32_t spp,
+               float *out_rgba, int32_t location, void *stream);
+
+/* Parity hook: closest hit of `world` for n given rays (HittableList::hit semantics,
+ * hittable_list.rs:39-50, without the stochastic ConstantMedium objects).
+ * rays_soa = 7 planes of n floats: ox oy oz dx dy dz time (math/src/ray.rs:10-14).
+ * prim_id = RT_MISS on miss.  normal3 = n x 3 (face-forwarded HitRecord.normal), uv2 = n x 2
+ * (may be NULL), front_face = n bytes.  All pointers are host pointers. */
+int rt_trace_first_hit(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_min, float t_max,
+                       uint32_t *prim_id, float *t, float *normal3, uint8_t *front_face, float *uv2);
+
+/* Block until everything queued on `stream` (NULL = default) by this context is done. */
+int rt_synchronize(rt_ctx *ctx, void *stream);
+
+/* Name, CU count and clock of the context's device (for bench reports). */
+int rt_device_info(rt_ctx *ctx, char *name, int32_t name_len, int32_t *cu_count, int32_t *clock_mhz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

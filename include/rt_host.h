@@ -1,0 +1,140 @@
+/*
+ * rt_host.h — C-ABI of the host side (librtiow_host.so): everything the reference does
+ * BEFORE the worker pool starts, restated so that it feeds the HIP backend.
+ *
+ *   RaytracerState::load_config + RaytracerParams::from   raytracer/src/main.rs:1178-1263
+ *   Camera::new                                            raytracer/src/camera.rs:39-80
+ *   MultiJitteredSampler::new                              raytracer/src/sampling.rs:30-135, 233-253
+ *   scene_random_world / scene_cornell_box /
+ *   scene_final_chapter2 / scene_mesh                      raytracer/src/main.rs:106-199, 362-522, 685-828, 969-1029
+ *   ImportedGeometry (GLB) + TriangleMesh::new             raytracer/src/geometry_import.rs:306-507, triangle_mesh.rs:43-119
+ *   "Hittable::flatten" (does not exist in the reference)  object tree -> flat arrays + BVH of include/rt_api.h
+ *
+ * No GPU code here; it builds and runs without HIP.  All functions return 0 on success and a
+ * negative rt_status otherwise; rth_last_error() gives the text (thread-local).
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include <stdint.h>
+#include "rt_api.h"
+#include "rt_scene_graph.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *rth_last_error(void);
+
+/* ------------------------------------------------------------------ scene graph building */
+typedef struct rth_scene rth_scene;
+
+rth_scene *rth_scene_new(void);
+void       rth_scene_free(rth_scene *s);
+/* The graph view stays valid until the next mutation of the scene. */
+const rtg_graph *rth_scene_graph(rth_scene *s);
+
+/* Textures / materials: constructors of the reference types; return the new index (>=0). */
+int rth_add_solid_texture(rth_scene *s, float r, float g, float b);               /* solid_color_texture.rs:9-13 */
+int rth_add_checker_texture(rth_scene *s, int odd_tex, int even_tex, float repeat); /* checker_texture.rs:23-33 */
+int rth_add_noise_texture(rth_scene *s, float scale, uint32_t seed);              /* noise_texture.rs:13-18 + perlin.rs:65-82 */
+int rth_add_image_texture(rth_scene *s, int width, int height, const uint8_t *rgba); /* image_texture.rs:40-47; 0x0 = blank() */
+int rth_add_lambertian(rth_scene *s, int albedo_tex);                             /* lambertian.rs:27-29 */
+int rth_add_metal(rth_scene *s, float r, float g, float b, float fuzz);           /* metal.rs:12-17 */
+int rth_add_dielectric(rth_scene *s, float ior);                                  /* dielectric.rs:11-13 */
+int rth_add_diffuse_light(rth_scene *s, int emit_tex);                            /* diffuse_light.rs:18-20 */
+int rth_add_isotropic(rth_scene *s, int albedo_tex);                              /* isotropic.rs:10-12 */
+
+/* Hittables; children are node indices.  Return the new node index. */
+int rth_add_sphere(rth_scene *s, const float c[3], float r, int mtl);
+int rth_add_moving_sphere(rth_scene *s, const float c0[3], const float c1[3], float t0, float t1, float r, int mtl);
+int rth_add_rect(rth_scene *s, int rtg_type /* RTG_XY_RECT.. */, float a0, float a1, float b0, float b1, float k, int mtl);
+int rth_add_block(rth_scene *s, const float p0[3], const float p1[3], int mtl);
+int rth_add_flip_face(rth_scene *s, int child);
+int rth_add_translate(rth_scene *s, int child, const float offset[3]);
+int rth_add_rotate_y(rth_scene *s, int child, float degrees);
+int rth_add_bvh(rth_scene *s, const int32_t *children, int n);
+int rth_add_list(rth_scene *s, const int32_t *children, int n);
+int rth_add_constant_medium(rth_scene *s, int boundary, int albedo_tex, float density);
+/* TriangleMesh::new: vertices are IMPORTED (object-space) vertices, obj2world row-major 4x4
+ * (math/src/mat4.rs:20-41); the call bakes them to world space as triangle_mesh.rs:48-72. */
+int rth_add_triangle_mesh(rth_scene *s, const rtg_vertex *verts, uint32_t n_verts, const uint32_t *indices,
+                          uint32_t n_indices, const rtg_mesh_node *nodes, uint32_t n_nodes,
+                          const float obj2world[16], int mtl);
+int rth_set_roots(rth_scene *s, int world_list, int lights_list);
+
+/* ------------------------------------------------------------------ glTF import */
+typedef struct rth_geometry rth_geometry;
+/* ImportedGeometry::import_from_file for a .glb (geometry only: positions, normals, uvs,
+ * indices, nodes; children before the node's own mesh; the importer's quaternion/matrix
+ * quirks of geometry_import.rs:314-329 are reproduced). */
+int  rth_geometry_import_glb(const char *path, rth_geometry **out);
+void rth_geometry_free(rth_geometry *g);
+void rth_geometry_view(const rth_geometry *g, const rtg_vertex **verts, uint32_t *n_verts, const uint32_t **indices,
+                       uint32_t *n_indices, const rtg_mesh_node **nodes, uint32_t *n_nodes);
+
+/* ------------------------------------------------------------------ the reference's scenes */
+typedef struct rth_image { int32_t width, height; const uint8_t *rgba; } rth_image;
+
+typedef struct rth_scene_assets {
+    rth_image earthmap;          /* data/textures/misc/earthmap.jpg      (Chapter2Final) */
+    rth_image uvgrid01;          /* data/textures/uv_grids/ash_uvgrid01.jpg (MeshTest floor) */
+    rth_image uvgrid09;          /* data/textures/uv_grids/ash_uvgrid09.jpg (MeshTest teapot) */
+    const rth_geometry *teapot;  /* data/models/teapot/teapot.glb        (MeshTest) */
+    int32_t mesh_grid;           /* MeshTest: K -> K x K baked copies of the mesh (1 = the reference scene) */
+} rth_scene_assets;
+
+/* name = a `Scene` variant of main.rs:93-104: "RandomWorld", "CornellBox", "Chapter2Final",
+ * "MeshTest".  seed feeds every random_* call of the builder (the reference is unseeded). */
+int rth_build_scene(rth_scene *s, const char *name, uint32_t seed, const rth_scene_assets *assets);
+
+/* ------------------------------------------------------------------ config (RON) */
+typedef struct rth_user_config {      /* RaytracerUserConfig, main.rs:1135-1154 */
+    int32_t workers, worker_block_pixels;
+    float   aspect_ratio;
+    int32_t image_width, samples_per_pixel, max_ray_depth;
+    float   vertical_fov;
+    float   look_from[3], look_at[3], world_up[3];
+    float   aperture, focus_dist;
+    int32_t shuffle_workblocks;
+    float   background[3];
+    int32_t projection;               /* 0 Perspective 1 Orthographic 2 FishEye 3 SphericalPanoramic */
+    float   psi_max, lambda_max;
+} rth_user_config;
+
+typedef struct rth_config rth_config;
+int  rth_config_load(const char *path, rth_config **out);       /* main.rs:1241-1246 */
+int  rth_config_parse(const char *text, rth_config **out);
+void rth_config_free(rth_config *c);
+const char *rth_config_active_scene(const rth_config *c);
+/* main.rs:1251-1261: params of `scene` (NULL = active scene); None -> default_params. */
+int  rth_config_scene_params(const rth_config *c, const char *scene, rth_user_config *out);
+/* RaytracerParams::from, main.rs:1180: image_height = (image_width / aspect_ratio) as i32 */
+int32_t rth_image_height(const rth_user_config *c);
+
+/* ------------------------------------------------------------------ camera + sampler */
+void rth_camera_new(const float look_from[3], const float look_at[3], const float world_up[3], float vfov_degrees,
+                    float aspect, float aperture, float focus_dist, float time0, float time1, rt_camera *out);
+
+typedef struct rth_sampler rth_sampler;
+/* MultiJitteredSampler::new(spp, None) with 83 sets when sets<=0.  Non-square spp (which
+ * panics in the reference, sampling.rs:235-251) is extended: see DESIGN.md. */
+int  rth_sampler_new(int32_t spp, int32_t sets, uint32_t seed, rth_sampler **out);
+void rth_sampler_free(rth_sampler *s);
+void rth_sampler_desc(const rth_sampler *s, rt_sampler_desc *out);
+
+/* ------------------------------------------------------------------ flatten */
+typedef struct rth_flat rth_flat;
+/* Lower the object tree to the arrays of rt_scene_desc and build the traversal BVH. */
+int  rth_flatten(const rtg_graph *g, rth_flat **out);
+void rth_flat_free(rth_flat *f);
+void rth_flat_desc(const rth_flat *f, rt_scene_desc *out);
+
+/* WorkBlock list of main.rs:1265-1282 (no shuffle): writes up to cap entries of x0,x1,y0,y1
+ * and returns the number of blocks. */
+int32_t rth_work_blocks(int32_t width, int32_t height, int32_t block_pixels, int32_t *out_xyxy, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

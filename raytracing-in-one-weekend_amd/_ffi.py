@@ -1,0 +1,260 @@
+"""ctypes view of include/rt_api.h, include/rt_host.h and include/rt_scene_graph.h.
+
+Only the two product libraries are loaded here.  There is no fallback: a missing
+librtiow_hip.so raises, it is never replaced by a CPU path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+c_float_p = C.POINTER(C.c_float)
+c_u32_p = C.POINTER(C.c_uint32)
+c_u8_p = C.POINTER(C.c_uint8)
+
+RT_OK = 0
+RT_MISS = 0xFFFFFFFF
+RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
+RTG_XY_RECT, RTG_XZ_RECT, RTG_YZ_RECT = 2, 3, 4
+
+STATUS_NAMES = {0: "RT_OK", -1: "RT_E_INVALID", -2: "RT_E_HIP", -3: "RT_E_RCCL", -4: "RT_E_OOM",
+                -5: "RT_E_UNSUPPORTED_PRIMITIVE", -6: "RT_E_NO_DEVICE", -7: "RT_E_CANCELLED"}
+
+
+class RtError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), text))
+        self.status = status
+
+
+class rt_scene_desc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("bvh_nodes", c_float_p), ("n_bvh_nodes", C.c_uint32),
+        ("bvh_root_ref", C.c_int32), ("bvh_stack_depth", C.c_uint32),
+        ("slots", c_float_p), ("n_slots", C.c_uint32),
+        ("always_begin", C.c_uint32), ("always_count", C.c_uint32),
+        ("tri_attrs", c_float_p),
+        ("xforms", c_float_p), ("n_xforms", C.c_uint32),
+        ("media", c_float_p), ("n_media", C.c_uint32),
+        ("lights", c_float_p), ("n_lights", C.c_uint32),
+        ("materials", c_float_p), ("n_materials", C.c_uint32),
+        ("textures", c_float_p), ("n_textures", C.c_uint32),
+        ("perlin", c_u32_p), ("n_perlin", C.c_uint32),
+        ("texels", c_u8_p), ("n_texel_bytes", C.c_uint64),
+        ("moving_slots", c_u32_p), ("n_moving_slots", C.c_uint32),
+        ("n_prims", C.c_uint32),
+    ]
+
+
+class rt_sampler_desc(C.Structure):
+    _fields_ = [("sets", C.c_uint32), ("samples_in_set", C.c_uint32), ("samples", c_float_p),
+                ("disk_samples", c_float_p), ("shuffled_indices", c_u32_p)]
+
+
+class rt_camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lower_left_corner", C.c_float * 3), ("horizontal", C.c_float * 3),
+                ("vertical", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3),
+                ("lens_radius", C.c_float), ("time0", C.c_float), ("time1", C.c_float)]
+
+
+class rt_render_params(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("image_width", C.c_int32), ("image_height", C.c_int32),
+        ("samples_per_pixel", C.c_int32), ("spp_begin", C.c_int32), ("spp_count", C.c_int32),
+        ("max_ray_depth", C.c_int32),
+        ("background", C.c_float * 3),
+        ("seed", C.c_uint32),
+        ("tile_x0", C.c_int32), ("tile_y0", C.c_int32), ("tile_x1", C.c_int32), ("tile_y1", C.c_int32),
+        ("camera", rt_camera),
+        ("out_location", C.c_int32),
+        ("stream", C.c_void_p),
+        ("cancel", C.POINTER(C.c_int32)),
+        ("collect_stats", C.c_int32),
+        ("pixel_rays", c_u32_p),
+    ]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64), ("box_tests", C.c_uint64),
+                ("prim_tests", C.c_uint64 * 6), ("medium_tests", C.c_uint64), ("light_pdf_evals", C.c_uint64),
+                ("shades", C.c_uint64 * 5), ("tex_evals", C.c_uint64 * 4), ("accepted_hits", C.c_uint64)]
+
+    def as_dict(self):
+        return {"paths": self.paths, "rays": self.rays, "node_visits": self.node_visits, "box_tests": self.box_tests,
+                "prim_tests": list(self.prim_tests), "medium_tests": self.medium_tests,
+                "light_pdf_evals": self.light_pdf_evals, "shades": list(self.shades),
+                "tex_evals": list(self.tex_evals), "accepted_hits": self.accepted_hits}
+
+
+class rtg_node(C.Structure):
+    _fields_ = [("type", C.c_int32), ("material", C.c_int32), ("child_begin", C.c_int32), ("child_count", C.c_int32),
+                ("f", C.c_float * 12), ("i", C.c_int32 * 4)]
+
+
+class rtg_material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("tex", C.c_int32), ("color", C.c_float * 3), ("fuzz", C.c_float),
+                ("ior", C.c_float), ("_pad", C.c_int32)]
+
+
+class rtg_texture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("odd", C.c_int32), ("even", C.c_int32),
+                ("scale", C.c_float), ("perlin", C.c_int32), ("image", C.c_int32), ("_pad", C.c_int32 * 3)]
+
+
+class rtg_vertex(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("normal", C.c_float * 3), ("uv", C.c_float * 2)]
+
+
+class rtg_mesh_node(C.Structure):
+    _fields_ = [("index_begin", C.c_uint32), ("index_count", C.c_uint32)]
+
+
+class rtg_mesh(C.Structure):
+    _fields_ = [("vertices", C.POINTER(rtg_vertex)), ("n_vertices", C.c_uint32), ("indices", c_u32_p),
+                ("n_indices", C.c_uint32), ("nodes", C.POINTER(rtg_mesh_node)), ("n_nodes", C.c_uint32)]
+
+
+class rtg_image(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgba", c_u8_p)]
+
+
+class rtg_graph(C.Structure):
+    _fields_ = [("nodes", C.POINTER(rtg_node)), ("n_nodes", C.c_uint32),
+                ("children", C.POINTER(C.c_int32)), ("n_children", C.c_uint32),
+                ("materials", C.POINTER(rtg_material)), ("n_materials", C.c_uint32),
+                ("textures", C.POINTER(rtg_texture)), ("n_textures", C.c_uint32),
+                ("perlins", C.c_void_p), ("n_perlins", C.c_uint32),
+                ("images", C.POINTER(rtg_image)), ("n_images", C.c_uint32),
+                ("meshes", C.POINTER(rtg_mesh)), ("n_meshes", C.c_uint32),
+                ("world_root", C.c_int32), ("lights_root", C.c_int32)]
+
+
+class rth_image(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgba", c_u8_p)]
+
+
+class rth_scene_assets(C.Structure):
+    _fields_ = [("earthmap", rth_image), ("uvgrid01", rth_image), ("uvgrid09", rth_image),
+                ("teapot", C.c_void_p), ("mesh_grid", C.c_int32)]
+
+
+class rth_user_config(C.Structure):
+    _fields_ = [("workers", C.c_int32), ("worker_block_pixels", C.c_int32), ("aspect_ratio", C.c_float),
+                ("image_width", C.c_int32), ("samples_per_pixel", C.c_int32), ("max_ray_depth", C.c_int32),
+                ("vertical_fov", C.c_float), ("look_from", C.c_float * 3), ("look_at", C.c_float * 3),
+                ("world_up", C.c_float * 3), ("aperture", C.c_float), ("focus_dist", C.c_float),
+                ("shuffle_workblocks", C.c_int32), ("background", C.c_float * 3), ("projection", C.c_int32),
+                ("psi_max", C.c_float), ("lambda_max", C.c_float)]
+
+
+HOST_SYMBOLS = [
+    "rth_last_error", "rth_scene_new", "rth_scene_free", "rth_scene_graph", "rth_add_solid_texture",
+    "rth_add_checker_texture", "rth_add_noise_texture", "rth_add_image_texture", "rth_add_lambertian", "rth_add_metal",
+    "rth_add_dielectric", "rth_add_diffuse_light", "rth_add_isotropic", "rth_add_sphere", "rth_add_moving_sphere",
+    "rth_add_rect", "rth_add_block", "rth_add_flip_face", "rth_add_translate", "rth_add_rotate_y", "rth_add_bvh",
+    "rth_add_list", "rth_add_constant_medium", "rth_add_triangle_mesh", "rth_set_roots", "rth_geometry_import_glb",
+    "rth_geometry_free", "rth_geometry_view", "rth_build_scene", "rth_config_load", "rth_config_parse",
+    "rth_config_free", "rth_config_active_scene", "rth_config_scene_params", "rth_image_height", "rth_camera_new",
+    "rth_sampler_new", "rth_sampler_free", "rth_sampler_desc", "rth_flatten", "rth_flat_free", "rth_flat_desc",
+    "rth_work_blocks",
+]
+
+HIP_SYMBOLS = [
+    "rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_scene_upload", "rt_sampler_upload", "rt_render",
+    "rt_resolve", "rt_trace_first_hit", "rt_synchronize", "rt_device_info",
+]
+
+_host = None
+_hip = None
+
+
+def host_lib():
+    """librtiow_host.so (no GPU needed)."""
+    global _host
+    if _host is not None:
+        return _host
+    path = os.path.join(LIB_DIR, "librtiow_host.so")
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: run __graft_entry__.build() (make -C raytracing-in-one-weekend_amd/csrc)" % path)
+    L = C.CDLL(path)
+    vp, i32, u32, f = C.c_void_p, C.c_int32, C.c_uint32, C.c_float
+    f3 = C.c_float * 3
+    L.rth_last_error.restype = C.c_char_p
+    L.rth_scene_new.restype = vp
+    L.rth_scene_free.argtypes = [vp]
+    L.rth_scene_graph.restype = C.POINTER(rtg_graph); L.rth_scene_graph.argtypes = [vp]
+    L.rth_add_solid_texture.argtypes = [vp, f, f, f]
+    L.rth_add_checker_texture.argtypes = [vp, i32, i32, f]
+    L.rth_add_noise_texture.argtypes = [vp, f, u32]
+    L.rth_add_image_texture.argtypes = [vp, i32, i32, c_u8_p]
+    L.rth_add_lambertian.argtypes = [vp, i32]
+    L.rth_add_metal.argtypes = [vp, f, f, f, f]
+    L.rth_add_dielectric.argtypes = [vp, f]
+    L.rth_add_diffuse_light.argtypes = [vp, i32]
+    L.rth_add_isotropic.argtypes = [vp, i32]
+    L.rth_add_sphere.argtypes = [vp, f3, f, i32]
+    L.rth_add_moving_sphere.argtypes = [vp, f3, f3, f, f, f, i32]
+    L.rth_add_rect.argtypes = [vp, i32, f, f, f, f, f, i32]
+    L.rth_add_block.argtypes = [vp, f3, f3, i32]
+    L.rth_add_flip_face.argtypes = [vp, i32]
+    L.rth_add_translate.argtypes = [vp, i32, f3]
+    L.rth_add_rotate_y.argtypes = [vp, i32, f]
+    L.rth_add_bvh.argtypes = [vp, C.POINTER(i32), i32]
+    L.rth_add_list.argtypes = [vp, C.POINTER(i32), i32]
+    L.rth_add_constant_medium.argtypes = [vp, i32, i32, f]
+    L.rth_add_triangle_mesh.argtypes = [vp, C.POINTER(rtg_vertex), u32, c_u32_p, u32, C.POINTER(rtg_mesh_node), u32,
+                                        C.c_float * 16, i32]
+    L.rth_set_roots.argtypes = [vp, i32, i32]
+    L.rth_geometry_import_glb.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.rth_geometry_free.argtypes = [vp]
+    L.rth_geometry_view.argtypes = [vp, C.POINTER(C.POINTER(rtg_vertex)), c_u32_p, C.POINTER(c_u32_p), c_u32_p,
+                                    C.POINTER(C.POINTER(rtg_mesh_node)), c_u32_p]
+    L.rth_geometry_view.restype = None
+    L.rth_build_scene.argtypes = [vp, C.c_char_p, u32, C.POINTER(rth_scene_assets)]
+    L.rth_config_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.rth_config_parse.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.rth_config_free.argtypes = [vp]
+    L.rth_config_active_scene.restype = C.c_char_p; L.rth_config_active_scene.argtypes = [vp]
+    L.rth_config_scene_params.argtypes = [vp, C.c_char_p, C.POINTER(rth_user_config)]
+    L.rth_image_height.argtypes = [C.POINTER(rth_user_config)]
+    L.rth_camera_new.argtypes = [f3, f3, f3, f, f, f, f, f, f, C.POINTER(rt_camera)]
+    L.rth_camera_new.restype = None
+    L.rth_sampler_new.argtypes = [i32, i32, u32, C.POINTER(vp)]
+    L.rth_sampler_free.argtypes = [vp]
+    L.rth_sampler_desc.argtypes = [vp, C.POINTER(rt_sampler_desc)]; L.rth_sampler_desc.restype = None
+    L.rth_flatten.argtypes = [C.POINTER(rtg_graph), C.POINTER(vp)]
+    L.rth_flat_free.argtypes = [vp]
+    L.rth_flat_desc.argtypes = [vp, C.POINTER(rt_scene_desc)]; L.rth_flat_desc.restype = None
+    L.rth_work_blocks.argtypes = [i32, i32, i32, C.POINTER(i32), i32]
+    _host = L
+    return L
+
+
+def hip_lib():
+    """librtiow_hip.so — the HIP backend.  Loading needs libamdhip64 but no GPU."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    path = os.path.join(LIB_DIR, "librtiow_hip.so")
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: the HIP extension is required, there is no CPU fallback "
+                          "(run __graft_entry__.build())" % path)
+    L = C.CDLL(path)
+    vp, i32 = C.c_void_p, C.c_int32
+    L.rt_device_count.restype = i32
+    L.rt_create.argtypes = [i32, C.POINTER(vp)]
+    L.rt_destroy.argtypes = [vp]; L.rt_destroy.restype = None
+    L.rt_last_error.argtypes = [vp]; L.rt_last_error.restype = C.c_char_p
+    L.rt_scene_upload.argtypes = [vp, C.POINTER(rt_scene_desc)]
+    L.rt_sampler_upload.argtypes = [vp, C.POINTER(rt_sampler_desc)]
+    L.rt_render.argtypes = [vp, C.POINTER(rt_render_params), C.c_void_p, C.POINTER(rt_stats)]
+    L.rt_resolve.argtypes = [vp, C.c_void_p, i32, i32, C.c_void_p, i32, vp]
+    L.rt_trace_first_hit.argtypes = [vp, c_float_p, i32, C.c_float, C.c_float, c_u32_p, c_float_p, c_float_p, c_u8_p,
+                                     c_float_p]
+    L.rt_synchronize.argtypes = [vp, vp]
+    L.rt_device_info.argtypes = [vp, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32)]
+    _hip = L
+    return L

@@ -1,0 +1,527 @@
+// rt_host_flatten.cpp — lower the object tree to flat arrays + a traversal BVH.
+//
+// This is the step the reference does not have: its scene is a tree of `Arc<dyn Hittable>`
+// (raytracer/src/hittable.rs:44-54) walked by virtual calls.  Here every leaf primitive
+// becomes one 64-byte slot; wrappers (flip_face.rs, transform.rs:9-153) become per-slot
+// flags; `BvhNode`s (bvh.rs) and `HittableList`s dissolve, because the kernels use their own
+// BVH over ALL leaves and reproduce the list semantics (closest hit, later object wins ties,
+// hittable_list.rs:39-50) by primitive id.  Layouts: include/rt_api.h.
+#include <algorithm>
+#include <cfloat>
+#include <numeric>
+
+#include "rt_host_internal.h"
+
+using namespace rth;
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() {
+        for (int a = 0; a < 3; ++a) { lo[a] = FLT_MAX; hi[a] = -FLT_MAX; }
+    }
+    void add(const float p[3]) {
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
+    }
+    void add(const Box &b) {
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); }
+    }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Slot {
+    float w[RT_SLOT_FLOATS];
+};
+struct Attr {
+    float w[RT_ATTR_FLOATS];
+};
+
+inline float i2f(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+
+struct Wrap {
+    bool flip = false;       // parity of FlipFace wrappers that act after the last Translate
+    bool has_rot = false, has_trans = false;
+    float sin_t = 0, cos_t = 1;
+    float off[3] = {0, 0, 0};
+    int xform = -1;
+};
+
+}  // namespace
+
+struct rth_flat {
+    std::vector<Slot> slots;
+    std::vector<Attr> attrs;
+    std::vector<float> nodes;  // RT_NODE_FLOATS each
+    std::vector<float> xforms, media, lights, materials, textures;
+    std::vector<uint32_t> perlin;
+    std::vector<uint8_t> texels;
+    std::vector<uint32_t> moving;
+    int32_t root_ref = RT_BVH_EMPTY;
+    uint32_t stack_depth = 1, always_begin = 0, always_count = 0, n_prims = 0;
+    bool has_tris = false;
+};
+
+namespace {
+
+struct Flattener {
+    const rtg_graph *g;
+    rth_flat *out;
+    std::vector<Slot> prims;   // in primitive-id order (before BVH reordering)
+    std::vector<Attr> pattrs;
+    std::vector<Box> boxes;
+    uint32_t next_id = 0;
+    std::string err;
+
+    bool fail(const std::string &m) {
+        if (err.empty()) err = m;
+        return false;
+    }
+
+    int xform_index(const Wrap &w) {
+        if (!w.has_rot && !w.has_trans) return -1;
+        float rec[RT_REC_FLOATS] = {};
+        rec[0] = i2f((w.has_rot ? 1 : 0) | (w.has_trans ? 2 : 0));
+        rec[1] = w.sin_t; rec[2] = w.cos_t;
+        rec[3] = w.off[0]; rec[4] = w.off[1]; rec[5] = w.off[2];
+        for (size_t i = 0; i + RT_REC_FLOATS <= out->xforms.size(); i += RT_REC_FLOATS)
+            if (memcmp(&out->xforms[i], rec, sizeof rec) == 0) return (int)(i / RT_REC_FLOATS);
+        out->xforms.insert(out->xforms.end(), rec, rec + RT_REC_FLOATS);
+        return (int)(out->xforms.size() / RT_REC_FLOATS) - 1;
+    }
+
+    // Object-space box -> world box through RotateY then Translate (the wrappers' own
+    // bounding_box code is not followed: any conservative box serves the traversal).
+    Box to_world(const Box &b, const Wrap &w) {
+        Box r;
+        r.reset();
+        for (int i = 0; i < 8; ++i) {
+            float p[3] = {(i & 1) ? b.hi[0] : b.lo[0], (i & 2) ? b.hi[1] : b.lo[1], (i & 4) ? b.hi[2] : b.lo[2]};
+            if (w.has_rot) {
+                float x = w.cos_t * p[0] + w.sin_t * p[2], z = -w.sin_t * p[0] + w.cos_t * p[2];
+                p[0] = x; p[2] = z;
+            }
+            if (w.has_trans) for (int a = 0; a < 3; ++a) p[a] += w.off[a];
+            r.add(p);
+        }
+        return r;
+    }
+
+    void emit(int type, const Wrap &w, int material, const float q0[4], float scalar, const float q2[4], const Box &obj_box,
+              const Attr *attr) {
+        Slot s{};
+        for (int i = 0; i < 4; ++i) { s.w[i] = q0[i]; s.w[8 + i] = q2 ? q2[i] : 0.0f; }
+        int xf = xform_index(w);
+        s.w[4] = i2f(type | (w.flip ? 16 : 0) | ((xf + 1) << 8));
+        s.w[5] = i2f(material);
+        s.w[6] = i2f((int32_t)next_id++);
+        s.w[7] = scalar;
+        Box wb = to_world(obj_box, w);
+        // Conservative padding: the slab test must never cull a primitive whose own hit test
+        // accepts the ray (DESIGN.md "BVH conservativeness").
+        float m = 1.0f;
+        for (int a = 0; a < 3; ++a) m = std::max(m, std::max(std::fabs(wb.lo[a]), std::fabs(wb.hi[a])));
+        float pad = 1.0e-4f * m;
+        for (int a = 0; a < 3; ++a) { wb.lo[a] -= pad; wb.hi[a] += pad; }
+        prims.push_back(s);
+        Attr a{};
+        if (attr) a = *attr;
+        pattrs.push_back(a);
+        boxes.push_back(wb);
+    }
+
+    void emit_rect(int gtype, const float *f, const Wrap &w, int material) {
+        // rectangles.rs: a = first in-plane axis, b = second, k = plane offset
+        float q0[4] = {f[0], f[1], f[2], f[3]};
+        float k = f[4];
+        Box b;
+        int type;
+        if (gtype == RTG_XY_RECT) { type = RT_PRIM_XY_RECT; b = Box{{f[0], f[2], k}, {f[1], f[3], k}}; }
+        else if (gtype == RTG_XZ_RECT) { type = RT_PRIM_XZ_RECT; b = Box{{f[0], k, f[2]}, {f[1], k, f[3]}}; }
+        else { type = RT_PRIM_YZ_RECT; b = Box{{k, f[0], f[2]}, {k, f[1], f[3]}}; }
+        emit(type, w, material, q0, k, nullptr, b, nullptr);
+    }
+
+    bool walk(int32_t idx, Wrap w, int depth) {
+        if (idx < 0 || (uint32_t)idx >= g->n_nodes) return fail("node index out of range");
+        if (depth > 64) return fail("scene graph nesting too deep");
+        const rtg_node &n = g->nodes[idx];
+        const int32_t *ch = g->children + n.child_begin;
+        switch (n.type) {
+        case RTG_SPHERE: {
+            float q0[4] = {n.f[0], n.f[1], n.f[2], n.f[3]};
+            float r = std::fabs(n.f[3]);
+            Box b{{n.f[0] - r, n.f[1] - r, n.f[2] - r}, {n.f[0] + r, n.f[1] + r, n.f[2] + r}};
+            emit(RT_PRIM_SPHERE, w, n.material, q0, 0.0f, nullptr, b, nullptr);
+            return true;
+        }
+        case RTG_MOVING_SPHERE: {
+            float r = std::fabs(n.f[8]);
+            float q0[4] = {n.f[0], n.f[1], n.f[2], n.f[8]};
+            float q2[4] = {n.f[3], n.f[4], n.f[5], n.f[7]};
+            Box b;
+            b.reset();
+            for (int e = 0; e < 2; ++e) {  // box over the shutter interval; rays with a time outside it
+                const float *c = n.f + 3 * e;  // are handled by the kernels' moving-sphere list
+                float lo[3] = {c[0] - r, c[1] - r, c[2] - r}, hi[3] = {c[0] + r, c[1] + r, c[2] + r};
+                b.add(lo); b.add(hi);
+            }
+            out->moving.push_back((uint32_t)prims.size());  // primitive order; remapped after the BVH build
+            emit(RT_PRIM_MOVING_SPHERE, w, n.material, q0, n.f[6], q2, b, nullptr);
+            return true;
+        }
+        case RTG_XY_RECT: case RTG_XZ_RECT: case RTG_YZ_RECT:
+            emit_rect(n.type, n.f, w, n.material);
+            return true;
+        case RTG_BLOCK: {  // block.rs:27-79: side order XY@z1, XY@z0, XZ@y1, XZ@y0, YZ@x1, YZ@x0
+            const float *p0 = n.f, *p1 = n.f + 3;
+            float xy1[5] = {p0[0], p1[0], p0[1], p1[1], p1[2]}, xy0[5] = {p0[0], p1[0], p0[1], p1[1], p0[2]};
+            float xz1[5] = {p0[0], p1[0], p0[2], p1[2], p1[1]}, xz0[5] = {p0[0], p1[0], p0[2], p1[2], p0[1]};
+            float yz1[5] = {p0[1], p1[1], p0[2], p1[2], p1[0]}, yz0[5] = {p0[1], p1[1], p0[2], p1[2], p0[0]};
+            emit_rect(RTG_XY_RECT, xy1, w, n.material); emit_rect(RTG_XY_RECT, xy0, w, n.material);
+            emit_rect(RTG_XZ_RECT, xz1, w, n.material); emit_rect(RTG_XZ_RECT, xz0, w, n.material);
+            emit_rect(RTG_YZ_RECT, yz1, w, n.material); emit_rect(RTG_YZ_RECT, yz0, w, n.material);
+            return true;
+        }
+        case RTG_FLIP_FACE:
+            // A FlipFace under a Translate is overwritten by Translate's HitRecord::new
+            // (transform.rs:36-44), so only flips met before the Translate count.
+            if (n.child_count != 1) return fail("FlipFace needs one child");
+            if (!w.has_trans) w.flip = !w.flip;
+            return walk(ch[0], w, depth + 1);
+        case RTG_TRANSLATE:
+            if (n.child_count != 1) return fail("Translate needs one child");
+            if (w.has_trans || w.has_rot) return fail("unsupported wrapper nesting: Translate under Translate/RotateY");
+            w.has_trans = true;
+            w.off[0] = n.f[0]; w.off[1] = n.f[1]; w.off[2] = n.f[2];
+            return walk(ch[0], w, depth + 1);
+        case RTG_ROTATE_Y: {
+            if (n.child_count != 1) return fail("RotateY needs one child");
+            if (w.has_rot) return fail("unsupported wrapper nesting: RotateY under RotateY");
+            float rads = (n.f[0] * 3.14159265358979323846f) / 180.0f;  // types.rs:44-46
+            pm::sincosf_(rads, &w.sin_t, &w.cos_t);
+            w.has_rot = true;
+            return walk(ch[0], w, depth + 1);
+        }
+        case RTG_BVH: case RTG_LIST:
+            for (int i = 0; i < n.child_count; ++i)
+                if (!walk(ch[i], w, depth + 1)) return false;
+            return true;
+        case RTG_CONSTANT_MEDIUM: {
+            if (n.child_count != 1) return fail("ConstantMedium needs one boundary");
+            if (w.has_rot || w.has_trans || w.flip) return fail("ConstantMedium under a wrapper is not supported");
+            const rtg_node &b = g->nodes[ch[0]];
+            if (b.type != RTG_SPHERE) return fail("ConstantMedium boundary must be a Sphere");
+            float rec[RT_REC_FLOATS] = {b.f[0], b.f[1], b.f[2], b.f[3], -1.0f / n.f[0] /* constant_medium.rs:24 */,
+                                        i2f(n.material), i2f((int32_t)next_id++), 0.0f};
+            out->media.insert(out->media.end(), rec, rec + RT_REC_FLOATS);
+            return true;
+        }
+        case RTG_TRIANGLE_MESH: {
+            if (n.i[0] < 0 || (uint32_t)n.i[0] >= g->n_meshes) return fail("mesh index out of range");
+            const rtg_mesh &m = g->meshes[n.i[0]];
+            out->has_tris = true;
+            for (uint32_t nd = 0; nd < m.n_nodes; ++nd)
+                for (uint32_t k = 0; k + 2 < m.nodes[nd].index_count; k += 3) {
+                    const uint32_t *ix = m.indices + m.nodes[nd].index_begin + k;
+                    const rtg_vertex &a = m.vertices[ix[0]], &b = m.vertices[ix[1]], &c = m.vertices[ix[2]];
+                    float q0[4] = {a.pos[0], a.pos[1], a.pos[2], b.pos[0]};
+                    float q2[4] = {b.pos[1], b.pos[2], c.pos[0], c.pos[1]};
+                    Box bx;
+                    bx.reset();
+                    bx.add(a.pos); bx.add(b.pos); bx.add(c.pos);
+                    Attr at{};
+                    memcpy(at.w + 0, a.normal, 12); memcpy(at.w + 3, b.normal, 12); memcpy(at.w + 6, c.normal, 12);
+                    memcpy(at.w + 9, a.uv, 8); memcpy(at.w + 11, b.uv, 8); memcpy(at.w + 13, c.uv, 8);
+                    emit(RT_PRIM_TRIANGLE, w, n.material, q0, c.pos[2], q2, bx, &at);
+                }
+            return true;
+        }
+        default:
+            return fail("unknown node type");
+        }
+    }
+
+    // lights list: pdf_value / random are forwarded WITHOUT transforming by Translate / RotateY
+    // (transform.rs:48-54, 146-152); FlipFace, Block, Bvh, ... keep the trait defaults
+    // (hittable.rs:47-53: pdf 0, random = unit_x) -> light type 255.
+    bool light(int32_t idx, int depth) {
+        if (idx < 0 || (uint32_t)idx >= g->n_nodes || depth > 64) return fail("bad light node");
+        const rtg_node &n = g->nodes[idx];
+        float rec[RT_REC_FLOATS] = {};
+        switch (n.type) {
+        case RTG_SPHERE:
+            rec[0] = i2f(RT_PRIM_SPHERE); rec[1] = n.f[0]; rec[2] = n.f[1]; rec[3] = n.f[2]; rec[4] = n.f[3];
+            break;
+        case RTG_XY_RECT: case RTG_XZ_RECT: case RTG_YZ_RECT:
+            rec[0] = i2f(n.type == RTG_XY_RECT ? RT_PRIM_XY_RECT : n.type == RTG_XZ_RECT ? RT_PRIM_XZ_RECT : RT_PRIM_YZ_RECT);
+            for (int i = 0; i < 5; ++i) rec[1 + i] = n.f[i];
+            break;
+        case RTG_TRANSLATE: case RTG_ROTATE_Y:
+            return light(g->children[n.child_begin], depth + 1);
+        case RTG_MOVING_SPHERE: case RTG_LIST:
+            return fail("MovingSphere / nested list in `lights` is not supported");
+        default:
+            rec[0] = i2f(255);
+            break;
+        }
+        out->lights.insert(out->lights.end(), rec, rec + RT_REC_FLOATS);
+        return true;
+    }
+};
+
+/* ------------------------------------------------------------------ BVH (binned SAH) */
+
+struct BuildNode {
+    Box box[2];
+    int32_t ref[2];
+};
+
+struct BvhBuilder {
+    const std::vector<Box> &boxes;
+    std::vector<uint32_t> order;        // primitive indices, leaves are contiguous runs
+    std::vector<float> cx, cy, cz;      // centroids
+    std::vector<BuildNode> nodes;
+    std::vector<std::pair<uint32_t, uint32_t>> leaves;  // (first, count) in `order`
+    uint32_t max_depth = 0;
+    static constexpr int kBins = 16, kLeafMax = 4, kDepthCap = 44;
+
+    explicit BvhBuilder(const std::vector<Box> &b) : boxes(b) {}
+
+    Box range_box(uint32_t b, uint32_t e) const {
+        Box r;
+        r.reset();
+        for (uint32_t i = b; i < e; ++i) r.add(boxes[order[i]]);
+        return r;
+    }
+    float centroid(uint32_t prim, int axis) const { return axis == 0 ? cx[prim] : axis == 1 ? cy[prim] : cz[prim]; }
+
+    // returns a ref: >=0 inner node, <0 leaf (~ref = leaf index here; remapped to slots later)
+    int32_t build(uint32_t b, uint32_t e, uint32_t depth) {
+        max_depth = std::max(max_depth, depth);
+        uint32_t n = e - b;
+        if (n <= (uint32_t)kLeafMax) {
+            leaves.emplace_back(b, n);
+            return ~(int32_t)(leaves.size() - 1);
+        }
+        // centroid bounds
+        float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (uint32_t i = b; i < e; ++i)
+            for (int a = 0; a < 3; ++a) {
+                float c = centroid(order[i], a);
+                clo[a] = std::min(clo[a], c); chi[a] = std::max(chi[a], c);
+            }
+        uint32_t mid = 0;
+        bool split_found = false;
+        // remaining depth budget: fall back to an exact median split when SAH could overrun it
+        uint32_t need = 0;
+        for (uint32_t m = (n + kLeafMax - 1) / kLeafMax; m > 1; m = (m + 1) / 2) ++need;
+        bool force_median = depth + need + 2 >= (uint32_t)kDepthCap;
+        int best_axis = -1;
+        if (!force_median) {
+            float best_cost = FLT_MAX;
+            int best_bin = -1;
+            for (int a = 0; a < 3; ++a) {
+                float ext = chi[a] - clo[a];
+                if (!(ext > 0.0f)) continue;
+                Box bin_box[kBins];
+                uint32_t bin_n[kBins] = {};
+                for (auto &bb : bin_box) bb.reset();
+                float scale = (float)kBins / ext;
+                for (uint32_t i = b; i < e; ++i) {
+                    int k = std::min(kBins - 1, (int)((centroid(order[i], a) - clo[a]) * scale));
+                    bin_box[k].add(boxes[order[i]]);
+                    ++bin_n[k];
+                }
+                float right_area[kBins];
+                Box acc;
+                acc.reset();
+                uint32_t cnt = 0;
+                for (int k = kBins - 1; k > 0; --k) {
+                    if (bin_n[k]) acc.add(bin_box[k]);
+                    right_area[k] = bin_n[k] || cnt ? acc.half_area() : 0.0f;
+                    cnt += bin_n[k];
+                }
+                acc.reset();
+                uint32_t left_n = 0;
+                for (int k = 0; k < kBins - 1; ++k) {
+                    if (bin_n[k]) acc.add(bin_box[k]);
+                    left_n += bin_n[k];
+                    uint32_t right_n = n - left_n;
+                    if (left_n == 0 || right_n == 0) continue;
+                    float cost = acc.half_area() * (float)left_n + right_area[k + 1] * (float)right_n;
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+                }
+            }
+            if (best_axis >= 0) {
+                float ext = chi[best_axis] - clo[best_axis];
+                float scale = (float)kBins / ext;
+                auto it = std::partition(order.begin() + b, order.begin() + e, [&](uint32_t p) {
+                    int k = std::min(kBins - 1, (int)((centroid(p, best_axis) - clo[best_axis]) * scale));
+                    return k <= best_bin;
+                });
+                mid = (uint32_t)(it - order.begin());
+                split_found = mid > b && mid < e;
+            }
+        }
+        if (!split_found) {  // median along the widest centroid axis
+            int a = 0;
+            for (int k = 1; k < 3; ++k)
+                if (chi[k] - clo[k] > chi[a] - clo[a]) a = k;
+            mid = b + n / 2;
+            std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e,
+                             [&](uint32_t p, uint32_t q) { return centroid(p, a) < centroid(q, a); });
+        }
+        int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        Box lb = range_box(b, mid), rb = range_box(mid, e);
+        int32_t l = build(b, mid, depth + 1);
+        int32_t r = build(mid, e, depth + 1);
+        nodes[me].box[0] = lb; nodes[me].box[1] = rb;
+        nodes[me].ref[0] = l; nodes[me].ref[1] = r;
+        return me;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rth_flatten(const rtg_graph *g, rth_flat **out_flat) {
+    if (!g || !out_flat) { set_error("null argument"); return RT_E_INVALID; }
+    if (g->world_root < 0 || g->lights_root < 0) { set_error("scene roots are not set"); return RT_E_INVALID; }
+    auto flat = std::make_unique<rth_flat>();
+    Flattener fl{g, flat.get(), {}, {}, {}, 0, {}};
+    if (!fl.walk(g->world_root, Wrap{}, 0)) {
+        set_error("flatten: %s", fl.err.c_str());
+        return RT_E_UNSUPPORTED_PRIMITIVE;
+    }
+    const rtg_node &ll = g->nodes[g->lights_root];
+    for (int i = 0; i < ll.child_count; ++i)
+        if (!fl.light(g->children[ll.child_begin + i], 0)) {
+            set_error("flatten: %s", fl.err.c_str());
+            return RT_E_UNSUPPORTED_PRIMITIVE;
+        }
+    flat->n_prims = fl.next_id;
+
+    // tables
+    for (uint32_t i = 0; i < g->n_materials; ++i) {
+        const rtg_material &m = g->materials[i];
+        float rec[RT_REC_FLOATS] = {i2f(m.type), i2f(m.tex), m.color[0], m.color[1], m.color[2], m.fuzz, m.ior, 0.0f};
+        flat->materials.insert(flat->materials.end(), rec, rec + RT_REC_FLOATS);
+    }
+    std::vector<uint64_t> image_offset(g->n_images);
+    for (uint32_t i = 0; i < g->n_images; ++i) {
+        image_offset[i] = flat->texels.size();
+        size_t bytes = (size_t)g->images[i].width * g->images[i].height * 4;
+        flat->texels.insert(flat->texels.end(), g->images[i].rgba, g->images[i].rgba + bytes);
+    }
+    if (flat->texels.size() > 0x7fffffffull * 4ull) { set_error("flatten: texel atlas too large"); return RT_E_INVALID; }
+    for (uint32_t i = 0; i < g->n_textures; ++i) {
+        const rtg_texture &t = g->textures[i];
+        float rec[RT_REC_FLOATS] = {i2f(t.type), t.color[0], t.color[1], t.color[2], 0, 0, 0, 0};
+        switch (t.type) {
+        case RTG_TEX_CHECKER: rec[4] = i2f(t.odd); rec[5] = i2f(t.even); rec[6] = t.scale; break;
+        case RTG_TEX_NOISE:   rec[4] = i2f(t.perlin); rec[6] = t.scale; break;
+        case RTG_TEX_IMAGE:
+            if (t.image >= 0) {
+                rec[4] = i2f((int32_t)(image_offset[t.image] / 4));  // texel (RGBA8 word) offset
+                rec[5] = i2f(g->images[t.image].width);
+                rec[7] = i2f(g->images[t.image].height);
+            } else {
+                rec[4] = i2f(-1);  // blank() -> cyan
+            }
+            break;
+        default: break;
+        }
+        flat->textures.insert(flat->textures.end(), rec, rec + RT_REC_FLOATS);
+    }
+    for (uint32_t i = 0; i < g->n_perlins; ++i) {
+        const rtg_perlin &p = g->perlins[i];
+        size_t base = flat->perlin.size();
+        flat->perlin.resize(base + RT_PERLIN_WORDS);
+        memcpy(&flat->perlin[base], p.ranvec, 256 * 3 * 4);
+        memcpy(&flat->perlin[base + 768], p.perm_x, 1024);
+        memcpy(&flat->perlin[base + 1024], p.perm_y, 1024);
+        memcpy(&flat->perlin[base + 1280], p.perm_z, 1024);
+    }
+
+    // BVH + slot order
+    size_t n = fl.prims.size();
+    std::vector<uint32_t> new_index(n);
+    if (n <= 16) {  // tiny scenes (Cornell box: 13 leaves): a flat scan beats any tree
+        flat->slots = fl.prims;
+        flat->attrs = fl.pattrs;
+        std::iota(new_index.begin(), new_index.end(), 0u);
+        flat->always_begin = 0;
+        flat->always_count = (uint32_t)n;
+        flat->root_ref = RT_BVH_EMPTY;
+        flat->stack_depth = 1;
+    } else {
+        BvhBuilder bb(fl.boxes);
+        bb.order.resize(n);
+        std::iota(bb.order.begin(), bb.order.end(), 0u);
+        bb.cx.resize(n); bb.cy.resize(n); bb.cz.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            bb.cx[i] = 0.5f * (fl.boxes[i].lo[0] + fl.boxes[i].hi[0]);
+            bb.cy[i] = 0.5f * (fl.boxes[i].lo[1] + fl.boxes[i].hi[1]);
+            bb.cz[i] = 0.5f * (fl.boxes[i].lo[2] + fl.boxes[i].hi[2]);
+        }
+        bb.nodes.reserve(n);
+        int32_t root = bb.build(0, (uint32_t)n, 0);
+        flat->slots.resize(n);
+        flat->attrs.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            flat->slots[i] = fl.prims[bb.order[i]];
+            flat->attrs[i] = fl.pattrs[bb.order[i]];
+            new_index[bb.order[i]] = (uint32_t)i;
+        }
+        auto leaf_ref = [&](int32_t r) -> int32_t {
+            if (r >= 0) return r;
+            auto lf = bb.leaves[~r];
+            return ~(int32_t)((lf.first << 3) | (lf.second - 1));
+        };
+        flat->nodes.resize(bb.nodes.size() * RT_NODE_FLOATS, 0.0f);
+        for (size_t i = 0; i < bb.nodes.size(); ++i) {
+            float *d = &flat->nodes[i * RT_NODE_FLOATS];
+            for (int c = 0; c < 2; ++c) {
+                memcpy(d + c * 6, bb.nodes[i].box[c].lo, 12);
+                memcpy(d + c * 6 + 3, bb.nodes[i].box[c].hi, 12);
+                d[12 + c] = i2f(leaf_ref(bb.nodes[i].ref[c]));
+            }
+        }
+        flat->root_ref = leaf_ref(root);
+        flat->stack_depth = bb.max_depth + 2;
+        flat->always_begin = flat->always_count = 0;
+    }
+    for (auto &m : flat->moving) m = new_index[m];
+    if (!flat->has_tris) flat->attrs.clear();
+    *out_flat = flat.release();
+    return RT_OK;
+}
+
+void rth_flat_free(rth_flat *f) { delete f; }
+
+void rth_flat_desc(const rth_flat *f, rt_scene_desc *d) {
+    memset(d, 0, sizeof *d);
+    d->struct_size = sizeof *d;
+    d->bvh_nodes = f->nodes.data();            d->n_bvh_nodes = (uint32_t)(f->nodes.size() / RT_NODE_FLOATS);
+    d->bvh_root_ref = f->root_ref;             d->bvh_stack_depth = f->stack_depth;
+    d->slots = f->slots.empty() ? nullptr : f->slots[0].w;   d->n_slots = (uint32_t)f->slots.size();
+    d->always_begin = f->always_begin;         d->always_count = f->always_count;
+    d->tri_attrs = f->attrs.empty() ? nullptr : f->attrs[0].w;
+    d->xforms = f->xforms.data();              d->n_xforms = (uint32_t)(f->xforms.size() / RT_REC_FLOATS);
+    d->media = f->media.data();                d->n_media = (uint32_t)(f->media.size() / RT_REC_FLOATS);
+    d->lights = f->lights.data();              d->n_lights = (uint32_t)(f->lights.size() / RT_REC_FLOATS);
+    d->materials = f->materials.data();        d->n_materials = (uint32_t)(f->materials.size() / RT_REC_FLOATS);
+    d->textures = f->textures.data();          d->n_textures = (uint32_t)(f->textures.size() / RT_REC_FLOATS);
+    d->perlin = f->perlin.data();              d->n_perlin = (uint32_t)(f->perlin.size() / RT_PERLIN_WORDS);
+    d->texels = f->texels.data();              d->n_texel_bytes = f->texels.size();
+    d->moving_slots = f->moving.data();        d->n_moving_slots = (uint32_t)f->moving.size();
+    d->n_prims = f->n_prims;
+}
+
+}  // extern "C"
