@@ -1,0 +1,121 @@
+"""The HIP render path behind include/rt_api.h (librtiow_hip.so).
+
+`HipBackend` stands where the reference's worker pool stands (raytracer/src/main.rs:1314-1409):
+it is given the camera, `world`/`lights` (flattened) and the sampler table, and fills
+`image_pixels`.  There is no CPU path here; without the library or a GPU it raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import RtError
+
+
+class HipBackend:
+    def __init__(self, device_id=0):
+        self._L = _ffi.hip_lib()
+        self._h = C.c_void_p()
+        st = self._L.rt_create(int(device_id), C.byref(self._h))
+        if st < 0:
+            raise RtError(st, self._L.rt_last_error(None).decode())
+        self.device_id = int(device_id)
+        self._flat = None
+        self._sampler = None
+
+    def _check(self, st):
+        if st < 0:
+            raise RtError(st, self._L.rt_last_error(self._h).decode())
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu, mhz = C.c_int32(), C.c_int32()
+        self._check(self._L.rt_device_info(self._h, name, 256, C.byref(cu), C.byref(mhz)))
+        return {"name": name.value.decode(), "cu_count": cu.value, "clock_mhz": mhz.value}
+
+    def upload_scene(self, flat):
+        """flat: host.FlatScene (or anything with a .desc rt_scene_desc)."""
+        self._check(self._L.rt_scene_upload(self._h, C.byref(flat.desc)))
+        self._flat = flat
+
+    def upload_sampler(self, sampler):
+        self._check(self._L.rt_sampler_upload(self._h, C.byref(sampler.desc)))
+        self._sampler = sampler
+
+    def _params(self, params, camera, seed, spp_begin, spp_count, tile, width, height):
+        W = width or params.image_width
+        H = height or params.image_height
+        p = _ffi.rt_render_params()
+        p.struct_size = C.sizeof(p)
+        p.image_width, p.image_height = W, H
+        p.samples_per_pixel = self._sampler.spp
+        p.spp_begin = spp_begin
+        p.spp_count = self._sampler.spp - spp_begin if spp_count is None else spp_count
+        p.max_ray_depth = params.max_ray_depth
+        p.background = (C.c_float * 3)(*params.background)
+        p.seed = seed
+        p.tile_x0, p.tile_y0, p.tile_x1, p.tile_y1 = tile if tile else (0, 0, W, H)
+        p.camera = camera
+        return p, W, H
+
+    def render(self, params, camera, seed=0x5EED, spp_begin=0, spp_count=None, tile=None, width=None, height=None,
+               out=None, stats=False, want_pixel_rays=False):
+        """Host-buffer render: returns (sum image HxWx4 f32, rt_stats dict or None[, pixel_rays])."""
+        p, W, H = self._params(params, camera, seed, spp_begin, spp_count, tile, width, height)
+        p.out_location = _ffi.RT_MEM_HOST
+        if out is None:
+            out = np.zeros((H, W, 4), np.float32)
+        assert out.dtype == np.float32 and out.shape == (H, W, 4) and out.flags.c_contiguous
+        st = _ffi.rt_stats()
+        pr = None
+        if stats or want_pixel_rays:
+            p.collect_stats = 1
+            if want_pixel_rays:
+                pr = np.zeros((H, W), np.uint32)
+                p.pixel_rays = pr.ctypes.data_as(_ffi.c_u32_p)
+        self._check(self._L.rt_render(self._h, C.byref(p), out.ctypes.data, C.byref(st)))
+        sd = st.as_dict() if p.collect_stats else None
+        return (out, sd, pr) if want_pixel_rays else (out, sd)
+
+    def render_device(self, params, camera, out_ptr, stream_ptr=None, seed=0x5EED, spp_begin=0, spp_count=None, tile=None,
+                      width=None, height=None):
+        """Asynchronous render into device memory (W*H*4 f32 at out_ptr) on the given HIP stream."""
+        p, W, H = self._params(params, camera, seed, spp_begin, spp_count, tile, width, height)
+        p.out_location = _ffi.RT_MEM_DEVICE
+        p.stream = stream_ptr
+        self._check(self._L.rt_render(self._h, C.byref(p), out_ptr, None))
+
+    def resolve(self, sum_rgba, spp):
+        s = np.ascontiguousarray(sum_rgba, np.float32)
+        out = np.zeros_like(s)
+        self._check(self._L.rt_resolve(self._h, s.ctypes.data, s.size // 4, spp, out.ctypes.data, _ffi.RT_MEM_HOST, None))
+        return out
+
+    def resolve_device(self, sum_ptr, n_pixels, spp, out_ptr, stream_ptr=None):
+        self._check(self._L.rt_resolve(self._h, sum_ptr, n_pixels, spp, out_ptr, _ffi.RT_MEM_DEVICE, stream_ptr))
+
+    def trace_first_hit(self, rays_soa, t_min=0.001, t_max=float("inf")):
+        rays_soa = np.ascontiguousarray(rays_soa, np.float32)
+        assert rays_soa.ndim == 2 and rays_soa.shape[0] == 7
+        n = rays_soa.shape[1]
+        pid = np.zeros(n, np.uint32); t = np.zeros(n, np.float32); nrm = np.zeros((n, 3), np.float32)
+        ff = np.zeros(n, np.uint8); uv = np.zeros((n, 2), np.float32)
+        self._check(self._L.rt_trace_first_hit(
+            self._h, rays_soa.ctypes.data_as(_ffi.c_float_p), n, t_min, t_max, pid.ctypes.data_as(_ffi.c_u32_p),
+            t.ctypes.data_as(_ffi.c_float_p), nrm.ctypes.data_as(_ffi.c_float_p), ff.ctypes.data_as(_ffi.c_u8_p),
+            uv.ctypes.data_as(_ffi.c_float_p)))
+        return pid, t, nrm, ff, uv
+
+    def synchronize(self, stream_ptr=None):
+        self._check(self._L.rt_synchronize(self._h, stream_ptr))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

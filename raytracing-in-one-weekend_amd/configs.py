@@ -1,0 +1,41 @@
+"""The BASELINE.json workloads as (scene, RaytracerParams) pairs.
+
+Cameras come from data/config/raytracer.config.ron where the reference ships one, with the
+image size / spp of BASELINE.json on top:
+  C1  RandomWorld    1200x675   10 spp   camera of stats.txt:1 (vfov 20, aspect 16/9)
+  C2  CornellBox      600x600 1000 spp   default_params camera, aspect 1.0
+  C3  Chapter2Final   800x800  10k spp   config camera
+  C4  MeshTest       1920x1080 256 spp   config camera, K x K teapots (K=10 -> 2.26 M triangles)
+"""
+from . import host
+
+SEED = 0x5EED
+
+WORKLOADS = {
+    "C1": dict(scene="RandomWorld", image_width=1200, aspect_ratio=1200.0 / 675.0, samples_per_pixel=10, vertical_fov=20.0),
+    "C2": dict(scene="CornellBox", image_width=600, aspect_ratio=1.0, samples_per_pixel=1000),
+    "C3": dict(scene="Chapter2Final", image_width=800, aspect_ratio=1.0, samples_per_pixel=10000),
+    "C4": dict(scene="MeshTest", image_width=1920, aspect_ratio=1920.0 / 1080.0, samples_per_pixel=256, mesh_grid=10),
+}
+
+
+def workload(name, config=None, **overrides):
+    """Returns (scene_name, RaytracerParams, mesh_grid)."""
+    w = dict(WORKLOADS[name])
+    w.update(overrides)
+    scene = w.pop("scene")
+    mesh_grid = w.pop("mesh_grid", 1)
+    cfg = config or host.RaytracerConfig.load()
+    params = cfg.scene_params(scene).replace(**w)
+    return scene, params, mesh_grid
+
+
+def build(name, config=None, seed=SEED, **overrides):
+    """Build everything a render needs: (Scene, RaytracerParams, rt_camera, MultiJitteredSampler)."""
+    scene_name, params, mesh_grid = workload(name, config, **overrides)
+    need = {"RandomWorld": (), "CornellBox": (), "Chapter2Final": ("earthmap",),
+            "MeshTest": ("uvgrid01", "uvgrid09", "teapot")}[scene_name]
+    assets = host.Assets(mesh_grid=mesh_grid, need=need) if need else None
+    scene = host.Scene.build(scene_name, seed, assets)
+    sampler = host.MultiJitteredSampler(params.samples_per_pixel, seed=seed)
+    return scene, params, params.camera(), sampler

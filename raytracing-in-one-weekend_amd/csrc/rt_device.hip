@@ -1,0 +1,404 @@
+// rt_device.hip — C-ABI of include/rt_api.h over the kernels of rt_kernels.h.
+//
+// Replaces the worker pool of RaytracerState::new (raytracer/src/main.rs:1314-1409).  One
+// rt_ctx = one GPU; scene and sampler tables stay resident in HBM between rt_render calls
+// (they are a few hundred KB to a few hundred MB; 288 GB leaves room for any of the
+// BASELINE scenes many times over), the accumulation image is the caller's.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_kernels.h"
+
+using namespace rtk;
+
+struct rt_ctx {
+    int device = 0;
+    std::string error;
+    hipStream_t stream = nullptr;  // library-owned stream for host-buffer calls
+    std::vector<void *> scene_allocs, sampler_allocs;
+    DScene sc{};
+    bool have_scene = false, have_sampler = false;
+    uint32_t stack_depth = 1;
+    unsigned long long *d_stats = nullptr;  // 32 counters
+    hipDeviceProp_t prop{};
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(rt_ctx *ctx, int status, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf; else g_create_error = buf;
+    return status;
+}
+
+#define HIP_TRY(ctx, call)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+void free_all(std::vector<void *> &v) {
+    for (void *p : v) (void)hipFree(p);
+    v.clear();
+}
+
+// Copy a host array to a fresh device allocation (at least 16 bytes so that empty tables still
+// have a valid, 16-byte-aligned address).
+template <class T>
+int upload(rt_ctx *ctx, std::vector<void *> &owner, const void *src, size_t bytes, const T **dst) {
+    void *d = nullptr;
+    size_t alloc = bytes < 64 ? 64 : bytes;
+    HIP_TRY(ctx, hipMalloc(&d, alloc));
+    owner.push_back(d);
+    HIP_TRY(ctx, hipMemsetAsync(d, 0, alloc < 4096 ? alloc : 64, ctx->stream));
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dst = static_cast<const T *>(d);
+    return RT_OK;
+}
+
+int set_device(rt_ctx *ctx) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_create(int device_id, rt_ctx **out) {
+    if (!out) return fail(nullptr, RT_E_INVALID, "rt_create: out is NULL");
+    *out = nullptr;
+    int n = rt_device_count();
+    if (n <= 0) return fail(nullptr, RT_E_NO_DEVICE, "no HIP device is visible");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, RT_E_INVALID, "device %d out of range (have %d)", device_id, n);
+    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return fail(nullptr, RT_E_OOM, "out of host memory");
+    ctx->device = device_id;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_stats, 32 * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        int st = fail(nullptr, RT_E_HIP, "rt_create: %s", hipGetErrorString(e));
+        delete ctx;
+        return st;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_all(ctx->scene_allocs);
+    free_all(ctx->sampler_allocs);
+    if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
+    if (!ctx) return RT_E_INVALID;
+    if (!s || s->struct_size != sizeof(rt_scene_desc)) return fail(ctx, RT_E_INVALID, "rt_scene_upload: bad descriptor size");
+    // shape checks: everything the kernels index must be consistent BEFORE anything is launched
+    if (s->n_slots && !s->slots) return fail(ctx, RT_E_INVALID, "slots missing");
+    if (s->n_bvh_nodes && !s->bvh_nodes) return fail(ctx, RT_E_INVALID, "bvh_nodes missing");
+    if (s->n_media > RT_MAX_MEDIA) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "at most %d ConstantMedium objects are supported", RT_MAX_MEDIA);
+    if (s->n_lights == 0) return fail(ctx, RT_E_INVALID, "`lights` is empty (the reference indexes objects[random_int(0,-1)], hittable_list.rs:71-75)");
+    if ((uint64_t)s->always_begin + s->always_count > s->n_slots) return fail(ctx, RT_E_INVALID, "always-list outside the slot array");
+    if (s->n_slots >= (1u << 28)) return fail(ctx, RT_E_INVALID, "too many primitives");
+    if (s->bvh_stack_depth == 0 || s->bvh_stack_depth > 64) return fail(ctx, RT_E_INVALID, "bvh_stack_depth %u out of range", s->bvh_stack_depth);
+    auto ref_ok = [&](int32_t ref) {
+        if (ref >= 0) return (uint32_t)ref < s->n_bvh_nodes;
+        uint32_t code = (uint32_t)~ref;
+        return (uint64_t)(code >> 3) + (code & 7u) + 1u <= s->n_slots;
+    };
+    if (s->bvh_root_ref != RT_BVH_EMPTY && !ref_ok(s->bvh_root_ref)) return fail(ctx, RT_E_INVALID, "bvh_root_ref out of range");
+    for (uint32_t i = 0; i < s->n_bvh_nodes; ++i) {
+        int32_t l, r;
+        memcpy(&l, &s->bvh_nodes[i * RT_NODE_FLOATS + 12], 4);
+        memcpy(&r, &s->bvh_nodes[i * RT_NODE_FLOATS + 13], 4);
+        if (!ref_ok(l) || !ref_ok(r)) return fail(ctx, RT_E_INVALID, "bvh node %u has a child out of range", i);
+    }
+    bool tris = false;
+    for (uint32_t i = 0; i < s->n_slots; ++i) {
+        int32_t w4, mat;
+        memcpy(&w4, &s->slots[i * RT_SLOT_FLOATS + 4], 4);
+        memcpy(&mat, &s->slots[i * RT_SLOT_FLOATS + 5], 4);
+        int type = w4 & 15, xf = (w4 >> 8) - 1;
+        if (type > RT_PRIM_TRIANGLE) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "slot %u: primitive type %d", i, type);
+        if (xf >= (int)s->n_xforms) return fail(ctx, RT_E_INVALID, "slot %u: xform out of range", i);
+        if (mat < 0 || (uint32_t)mat >= s->n_materials) return fail(ctx, RT_E_INVALID, "slot %u: material out of range", i);
+        tris |= type == RT_PRIM_TRIANGLE;
+    }
+    if (tris && !s->tri_attrs) return fail(ctx, RT_E_INVALID, "triangles without tri_attrs");
+    for (uint32_t i = 0; i < s->n_moving_slots; ++i)
+        if (s->moving_slots[i] >= s->n_slots) return fail(ctx, RT_E_INVALID, "moving slot out of range");
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        int32_t type, tex;
+        memcpy(&type, &s->materials[i * RT_REC_FLOATS], 4);
+        memcpy(&tex, &s->materials[i * RT_REC_FLOATS + 1], 4);
+        if (type < 0 || type > RTG_MAT_ISOTROPIC) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "material %u: type %d", i, type);
+        bool textured = type == RTG_MAT_LAMBERTIAN || type == RTG_MAT_DIFFUSE_LIGHT || type == RTG_MAT_ISOTROPIC;
+        if (textured && (tex < 0 || (uint32_t)tex >= s->n_textures)) return fail(ctx, RT_E_INVALID, "material %u: texture out of range", i);
+    }
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        int32_t w[8];
+        memcpy(w, &s->textures[i * RT_REC_FLOATS], 32);
+        if (w[0] < 0 || w[0] > RTG_TEX_IMAGE) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "texture %u: type %d", i, w[0]);
+        if (w[0] == RTG_TEX_CHECKER && (w[4] < 0 || w[5] < 0 || (uint32_t)w[4] >= s->n_textures || (uint32_t)w[5] >= s->n_textures))
+            return fail(ctx, RT_E_INVALID, "texture %u: checker child out of range", i);
+        if (w[0] == RTG_TEX_NOISE && (w[4] < 0 || (uint32_t)w[4] >= s->n_perlin)) return fail(ctx, RT_E_INVALID, "texture %u: perlin table out of range", i);
+        if (w[0] == RTG_TEX_IMAGE && w[4] >= 0 && (w[5] <= 0 || w[7] <= 0 || ((uint64_t)w[4] + (uint64_t)w[5] * (uint64_t)w[7]) * 4 > s->n_texel_bytes))
+            return fail(ctx, RT_E_INVALID, "texture %u: image outside the texel atlas", i);
+    }
+    for (uint32_t i = 0; i < s->n_media; ++i) {
+        int32_t mat;
+        memcpy(&mat, &s->media[i * RT_REC_FLOATS + 5], 4);
+        if (mat < 0 || (uint32_t)mat >= s->n_materials) return fail(ctx, RT_E_INVALID, "medium %u: material out of range", i);
+    }
+
+    int st = set_device(ctx);
+    if (st) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_all(ctx->scene_allocs);
+    ctx->have_scene = false;
+    DScene &d = ctx->sc;
+    auto &own = ctx->scene_allocs;
+#define UP(field, src, bytes) if ((st = upload(ctx, own, src, bytes, &d.field)) != RT_OK) return st
+    UP(nodes, s->bvh_nodes, (size_t)s->n_bvh_nodes * RT_NODE_FLOATS * 4);
+    UP(slots, s->slots, (size_t)s->n_slots * RT_SLOT_FLOATS * 4);
+    UP(attrs, s->tri_attrs, tris ? (size_t)s->n_slots * RT_ATTR_FLOATS * 4 : 0);
+    UP(xforms, s->xforms, (size_t)s->n_xforms * RT_REC_FLOATS * 4);
+    UP(media, s->media, (size_t)s->n_media * RT_REC_FLOATS * 4);
+    UP(lights, s->lights, (size_t)s->n_lights * RT_REC_FLOATS * 4);
+    UP(materials, s->materials, (size_t)s->n_materials * RT_REC_FLOATS * 4);
+    UP(textures, s->textures, (size_t)s->n_textures * RT_REC_FLOATS * 4);
+    UP(perlin, s->perlin, (size_t)s->n_perlin * RT_PERLIN_WORDS * 4);
+    UP(texels, s->texels, (size_t)s->n_texel_bytes);
+    UP(moving, s->moving_slots, (size_t)s->n_moving_slots * 4);
+#undef UP
+    d.root_ref = s->bvh_root_ref;
+    d.n_slots = s->n_slots;
+    d.always_begin = s->always_begin; d.always_count = s->always_count;
+    d.n_media = s->n_media; d.n_lights = s->n_lights; d.n_moving = s->n_moving_slots;
+    ctx->stack_depth = s->bvh_stack_depth;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_scene = true;
+    return RT_OK;
+}
+
+int rt_sampler_upload(rt_ctx *ctx, const rt_sampler_desc *s) {
+    if (!ctx) return RT_E_INVALID;
+    if (!s || !s->samples || !s->disk_samples || !s->shuffled_indices || s->sets == 0 || s->samples_in_set == 0)
+        return fail(ctx, RT_E_INVALID, "rt_sampler_upload: bad descriptor");
+    size_t n = (size_t)s->sets * s->samples_in_set;
+    for (size_t i = 0; i < n; ++i)
+        if (s->shuffled_indices[i] >= s->samples_in_set) return fail(ctx, RT_E_INVALID, "shuffled index %zu out of range", i);
+    int st = set_device(ctx);
+    if (st) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_all(ctx->sampler_allocs);
+    ctx->have_sampler = false;
+    auto &own = ctx->sampler_allocs;
+    if ((st = upload(ctx, own, s->samples, n * 8, &ctx->sc.samples)) != RT_OK) return st;
+    if ((st = upload(ctx, own, s->disk_samples, n * 8, &ctx->sc.disk)) != RT_OK) return st;
+    if ((st = upload(ctx, own, s->shuffled_indices, n * 4, &ctx->sc.shuffled)) != RT_OK) return st;
+    ctx->sc.sets = s->sets;
+    ctx->sc.spp = s->samples_in_set;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_sampler = true;
+    return RT_OK;
+}
+
+int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_stats *stats) {
+    if (!ctx) return RT_E_INVALID;
+    if (!p || p->struct_size != sizeof(rt_render_params) || !out_rgba_sum) return fail(ctx, RT_E_INVALID, "rt_render: bad arguments");
+    if (!ctx->have_scene || !ctx->have_sampler) return fail(ctx, RT_E_INVALID, "rt_render: upload a scene and a sampler first");
+    if (p->image_width < 2 || p->image_height < 2) return fail(ctx, RT_E_INVALID, "image must be at least 2x2 (u divides by W-1, camera.rs:197)");
+    if ((int64_t)p->image_width * p->image_height > (1ll << 30)) return fail(ctx, RT_E_INVALID, "image too large");
+    if (p->samples_per_pixel != (int32_t)ctx->sc.spp) return fail(ctx, RT_E_INVALID, "samples_per_pixel %d does not match the sampler table (%u)", p->samples_per_pixel, ctx->sc.spp);
+    if (p->spp_begin < 0 || p->spp_count < 0 || p->spp_begin + p->spp_count > p->samples_per_pixel) return fail(ctx, RT_E_INVALID, "sample range outside [0, spp)");
+    if (p->collect_stats && !stats) return fail(ctx, RT_E_INVALID, "collect_stats without a stats struct");
+    int x0 = p->tile_x0 < 0 ? 0 : p->tile_x0, y0 = p->tile_y0 < 0 ? 0 : p->tile_y0;
+    int x1 = p->tile_x1 > p->image_width ? p->image_width : p->tile_x1, y1 = p->tile_y1 > p->image_height ? p->image_height : p->tile_y1;
+    if (p->cancel && *p->cancel) return fail(ctx, RT_E_CANCELLED, "cancelled");
+    if (x1 <= x0 || y1 <= y0 || p->spp_count == 0) return RT_OK;
+    int st = set_device(ctx);
+    if (st) return st;
+
+    RenderArgs a{};
+    a.width = p->image_width; a.height = p->image_height;
+    a.spp = p->samples_per_pixel; a.spp_begin = p->spp_begin; a.spp_count = p->spp_count;
+    a.max_depth = p->max_ray_depth;
+    memcpy(a.bg, p->background, sizeof a.bg);
+    a.seed = p->seed;
+    a.x0 = x0; a.y0 = y0; a.x1 = x1; a.y1 = y1;
+    a.cam = p->camera;
+
+    const bool host_out = p->out_location == RT_MEM_HOST;
+    hipStream_t stream = host_out ? ctx->stream : (p->stream ? (hipStream_t)p->stream : nullptr);
+    size_t n_px = (size_t)p->image_width * p->image_height;
+    float4 *d_out = reinterpret_cast<float4 *>(out_rgba_sum);
+    uint32_t *d_rays = p->collect_stats ? p->pixel_rays : nullptr;
+    void *tmp_out = nullptr, *tmp_rays = nullptr;
+    if (host_out) {
+        HIP_TRY(ctx, hipMalloc(&tmp_out, n_px * 16));
+        hipError_t e = hipMemcpyAsync(tmp_out, out_rgba_sum, n_px * 16, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess && d_rays) {
+            e = hipMalloc(&tmp_rays, n_px * 4);
+            if (e == hipSuccess) e = hipMemcpyAsync(tmp_rays, p->pixel_rays, n_px * 4, hipMemcpyHostToDevice, stream);
+        }
+        if (e != hipSuccess) {
+            (void)hipFree(tmp_out);
+            if (tmp_rays) (void)hipFree(tmp_rays);
+            return fail(ctx, RT_E_HIP, "staging the image failed: %s", hipGetErrorString(e));
+        }
+        d_out = static_cast<float4 *>(tmp_out);
+        if (d_rays) d_rays = static_cast<uint32_t *>(tmp_rays);
+    }
+    int tiles_x = (x1 - x0 + 15) / 16, tiles_y = (y1 - y0 + 15) / 16;
+    dim3 grid((unsigned)(tiles_x * tiles_y)), block(256);
+    size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(uint2);
+    hipError_t e = hipSuccess;
+    if (p->collect_stats) {
+        e = hipMemsetAsync(ctx->d_stats, 0, 32 * sizeof(unsigned long long), stream);
+        if (e == hipSuccess) hipLaunchKernelGGL(render_kernel<true>, grid, block, lds, stream, ctx->sc, a, d_out, ctx->d_stats, d_rays);
+    } else {
+        hipLaunchKernelGGL(render_kernel<false>, grid, block, lds, stream, ctx->sc, a, d_out, (unsigned long long *)nullptr, (uint32_t *)nullptr);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    unsigned long long h_stats[32] = {};
+    if (e == hipSuccess && p->collect_stats) {
+        e = hipMemcpyAsync(h_stats, ctx->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    }
+    if (e == hipSuccess && host_out) {
+        e = hipMemcpyAsync(out_rgba_sum, tmp_out, n_px * 16, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess && tmp_rays) e = hipMemcpyAsync(p->pixel_rays, tmp_rays, n_px * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    }
+    if (tmp_out) (void)hipFree(tmp_out);
+    if (tmp_rays) (void)hipFree(tmp_rays);
+    if (e != hipSuccess) return fail(ctx, RT_E_HIP, "rt_render: %s", hipGetErrorString(e));
+    if (p->collect_stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->paths = h_stats[0]; stats->rays = h_stats[1]; stats->node_visits = h_stats[2];
+        stats->box_tests = 2 * h_stats[2];
+        for (int i = 0; i < 6; ++i) stats->prim_tests[i] = h_stats[3 + i];
+        stats->medium_tests = h_stats[9]; stats->light_pdf_evals = h_stats[10];
+        for (int i = 0; i < 5; ++i) stats->shades[i] = h_stats[11 + i];
+        for (int i = 0; i < 4; ++i) stats->tex_evals[i] = h_stats[16 + i];
+        stats->accepted_hits = h_stats[20];
+    }
+    return RT_OK;
+}
+
+int rt_resolve(rt_ctx *ctx, const float *rgba_sum, int32_t n_pixels, int32_t spp, float *out_rgba, int32_t location, void *stream_) {
+    if (!ctx) return RT_E_INVALID;
+    if (!rgba_sum || !out_rgba || n_pixels < 0 || spp <= 0) return fail(ctx, RT_E_INVALID, "rt_resolve: bad arguments");
+    if (n_pixels == 0) return RT_OK;
+    int st = set_device(ctx);
+    if (st) return st;
+    float inv_spp = 1.0f / (float)spp;  // (spp as f32).recip(), main.rs:1363
+    dim3 grid((unsigned)((n_pixels + 255) / 256)), block(256);
+    if (location == RT_MEM_DEVICE) {
+        hipStream_t stream = stream_ ? (hipStream_t)stream_ : nullptr;
+        hipLaunchKernelGGL(resolve_kernel, grid, block, 0, stream, (const float4 *)rgba_sum, n_pixels, inv_spp, (float4 *)out_rgba);
+        HIP_TRY(ctx, hipGetLastError());
+        return RT_OK;
+    }
+    void *d_in = nullptr, *d_o = nullptr;
+    size_t bytes = (size_t)n_pixels * 16;
+    HIP_TRY(ctx, hipMalloc(&d_in, bytes));
+    hipError_t e = hipMalloc(&d_o, bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, rgba_sum, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(resolve_kernel, grid, block, 0, ctx->stream, (const float4 *)d_in, n_pixels, inv_spp, (float4 *)d_o);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_rgba, d_o, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in);
+    if (d_o) (void)hipFree(d_o);
+    if (e != hipSuccess) return fail(ctx, RT_E_HIP, "rt_resolve: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_trace_first_hit(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_min, float t_max, uint32_t *prim_id, float *t,
+                       float *normal3, uint8_t *front_face, float *uv2) {
+    if (!ctx) return RT_E_INVALID;
+    if (!rays_soa || n < 0 || !prim_id || !t || !normal3 || !front_face) return fail(ctx, RT_E_INVALID, "rt_trace_first_hit: bad arguments");
+    if (!ctx->have_scene) return fail(ctx, RT_E_INVALID, "rt_trace_first_hit: upload a scene first");
+    if (n == 0) return RT_OK;
+    int st = set_device(ctx);
+    if (st) return st;
+    size_t N = (size_t)n;
+    char *d = nullptr;
+    // one allocation: rays 28N | prim 4N | t 4N | normal 12N | uv 8N | ff N
+    size_t off_prim = 28 * N, off_t = 32 * N, off_n = 36 * N, off_uv = 48 * N, off_ff = 56 * N, total = 57 * N;
+    HIP_TRY(ctx, hipMalloc((void **)&d, total));
+    hipStream_t stream = ctx->stream;
+    hipError_t e = hipMemcpyAsync(d, rays_soa, 28 * N, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        dim3 grid((unsigned)((N + 255) / 256)), block(256);
+        size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(uint2);
+        hipLaunchKernelGGL(first_hit_kernel, grid, block, lds, stream, ctx->sc, (const float *)d, n, t_min, t_max,
+                           (uint32_t *)(d + off_prim), (float *)(d + off_t), (float *)(d + off_n), (uint8_t *)(d + off_ff),
+                           (float *)(d + off_uv));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(prim_id, d + off_prim, 4 * N, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t, d + off_t, 4 * N, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(normal3, d + off_n, 12 * N, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(front_face, d + off_ff, N, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && uv2) e = hipMemcpyAsync(uv2, d + off_uv, 8 * N, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, RT_E_HIP, "rt_trace_first_hit: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_synchronize(rt_ctx *ctx, void *stream) {
+    if (!ctx) return RT_E_INVALID;
+    int st = set_device(ctx);
+    if (st) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : nullptr));
+    return RT_OK;
+}
+
+int rt_device_info(rt_ctx *ctx, char *name, int32_t name_len, int32_t *cu_count, int32_t *clock_mhz) {
+    if (!ctx) return RT_E_INVALID;
+    if (name && name_len > 0) {
+        strncpy(name, ctx->prop.name, (size_t)name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = ctx->prop.clockRate / 1000;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,925 @@
+// rt_kernels.h — device code of the path tracer (gfx950).
+//
+// One lane carries one camera path at a time and regenerates a new sample of ITS pixel as
+// soon as the path ends, so a wave stays full until its 8x8 pixel tile has no samples left
+// (persistent lanes instead of the reference's per-pixel fold, camera.rs:186-251).
+// `ray_color` (camera.rs:253-309) is evaluated front-to-back: the recursion
+//     L = e0 + w0 * (e1 + w1 * (...))      is accumulated as      L += T*e_k ; T *= w_k.
+// Everything that decides WHERE a path goes (hit tests, scatter directions, pdfs, random
+// draws) follows the reference operation by operation — single IEEE f32 operations, no
+// contraction — so a path is bit-identical to the CPU oracle's; only the radiance products
+// are associated differently (<= a few ulp per bounce).
+//
+// The closest-hit search is the part that is NOT the reference's algorithm: a 2-wide BVH over
+// ALL leaf primitives (64-byte nodes holding both child boxes, 64-byte primitive slots),
+// traversed with a per-lane stack in LDS.  It reproduces HittableList::hit semantics
+// (hittable_list.rs:39-50): closest t, and on an exact tie the object later in the list —
+// the larger primitive id — wins.
+#ifndef RT_KERNELS_H
+#define RT_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_api.h"
+#include "rt_portable_math.h"
+#include "rt_scene_graph.h"
+#include "rt_seed_schedule.h"
+
+#pragma clang fp contract(off)
+
+namespace rtk {
+
+#define RT_DEV __device__ __forceinline__
+#define RT_MAX_MEDIA 4
+#define RT_F32_MAX 3.40282347e+38f
+
+struct V3 {
+    float x, y, z;
+};
+RT_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+RT_DEV V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_DEV V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_DEV V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+RT_DEV V3 operator*(V3 a, float k) { return {a.x * k, a.y * k, a.z * k}; }
+RT_DEV V3 operator*(float k, V3 a) { return {a.x * k, a.y * k, a.z * k}; }
+RT_DEV V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+RT_DEV V3 operator/(V3 a, float k) { return {a.x / k, a.y / k, a.z / k}; }
+RT_DEV float length_squared(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+RT_DEV float length(V3 v) { return sqrtf(length_squared(v)); }
+RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+RT_DEV V3 normalize(V3 v) {  // math/src/vec3.rs:690-700
+    float lensq = length_squared(v);
+    if (lensq == 0.0f) return v3(0.0f, 0.0f, 0.0f);
+    return v * (1.0f / sqrtf(lensq));
+}
+RT_DEV V3 reflect_unit_vector(V3 v, V3 n) {  // vec3.rs:740-753
+    float two = 2.0f;
+    return v - two * dot(v, n) * n;
+}
+RT_DEV V3 refract(V3 uv, V3 n, float eta) {  // vec3.rs:756-771
+    float cos_theta = dot(-uv, n);
+    V3 r_par = eta * (uv + cos_theta * n);
+    V3 r_perp = -sqrtf(1.0f - length_squared(r_par)) * n;
+    return r_par + r_perp;
+}
+RT_DEV float f32_min(float a, float b) { return a != a ? b : (b != b ? a : (a < b ? a : b)); }
+RT_DEV float f32_clamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+RT_DEV int f2i(float f) { return __float_as_int(f); }
+
+struct Ray {
+    V3 o, d;
+    float time;
+    RT_DEV V3 at(float t) const { return o + t * d; }
+};
+
+struct DScene {
+    const float4 *nodes;
+    const float4 *slots;
+    const float4 *attrs;
+    const float4 *xforms;     // 2 x float4 per record
+    const float4 *media;
+    const float4 *lights;
+    const float4 *materials;
+    const float4 *textures;
+    const uint32_t *perlin;
+    const uint32_t *texels;
+    const uint32_t *moving;
+    const float2 *samples;
+    const float2 *disk;
+    const uint32_t *shuffled;
+    int32_t root_ref;
+    uint32_t n_slots, always_begin, always_count, n_media, n_lights, n_moving, sets, spp;
+};
+
+struct Counters {  // only live in the STATS instantiation
+    uint32_t rays, node_visits, prim_tests[6], medium_tests, light_pdf_evals, shades[5], tex_evals[4], accepted;
+};
+
+struct Hit {      // what the search tracks
+    float t;
+    int32_t id;   // primitive id (tie-break key); -1 = nothing
+    int32_t slot; // slot index, or -(medium index + 1)
+};
+
+struct Rec {      // HitRecord (hittable.rs:6-14)
+    V3 p, normal;
+    float t, u, v;
+    bool front_face;
+    int32_t material;
+};
+
+/* ------------------------------------------------------------------ primitive tests */
+
+// Ray into the frame of a wrapped primitive: Translate (transform.rs:34) then RotateY (:117-126).
+RT_DEV Ray to_object(const DScene &sc, int xf, const Ray &r) {
+    float4 a = sc.xforms[2 * xf], b = sc.xforms[2 * xf + 1];
+    int flags = f2i(a.x);
+    float sin_t = a.y, cos_t = a.z;
+    Ray q = r;
+    if (flags & 2) q.o = r.o - v3(a.w, b.x, b.y);
+    if (flags & 1) {
+        V3 o = q.o, d = q.d;
+        q.o.x = cos_t * o.x - sin_t * o.z;
+        q.o.z = sin_t * o.x + cos_t * o.z;
+        q.d.x = cos_t * d.x - sin_t * d.z;
+        q.d.z = sin_t * d.x + cos_t * d.z;
+    }
+    return q;
+}
+
+RT_DEV bool sphere_roots(V3 center, float radius, const Ray &r, float t_min, float t_max, float *t_out) {  // sphere.rs:45-66
+    V3 oc = r.o - center;
+    float a = length_squared(r.d);
+    float half_b = dot(oc, r.d);
+    float c = length_squared(oc) - radius * radius;
+    float disc = half_b * half_b - a * c;
+    if (disc < 0.0f) return false;
+    float sqrtd = sqrtf(disc);
+    float root = (-half_b - sqrtd) / a;
+    if (root < t_min || t_max < root) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || t_max < root) return false;
+    }
+    *t_out = root;
+    return true;
+}
+
+RT_DEV V3 moving_center(float4 q0, float time0, float4 q2, float time) {  // sphere.rs:144-147
+    V3 c0 = v3(q0.x, q0.y, q0.z), c1 = v3(q2.x, q2.y, q2.z);
+    return c0 + ((time - time0) / (q2.w - time0)) * (c1 - c0);
+}
+
+RT_DEV float comp(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+// rectangles.rs:22-34 / 92-104 / 162-174.  type: 2 XY (A=x,B=y,AX=z) 3 XZ (x,z,y) 4 YZ (y,z,x)
+RT_DEV bool rect_test(int type, float4 q0, float k, const Ray &r, float t_min, float t_max, float *t_out, float *a_out, float *b_out) {
+    int AX = type == RT_PRIM_XY_RECT ? 2 : (type == RT_PRIM_XZ_RECT ? 1 : 0);
+    int A = type == RT_PRIM_YZ_RECT ? 1 : 0;
+    int B = type == RT_PRIM_XY_RECT ? 1 : 2;
+    float t = (k - comp(r.o, AX)) / comp(r.d, AX);
+    if (t < t_min || t > t_max) return false;
+    float a = comp(r.o, A) + t * comp(r.d, A);
+    float b = comp(r.o, B) + t * comp(r.d, B);
+    if (a < q0.x || a > q0.y || b < q0.z || b > q0.w) return false;
+    *t_out = t; *a_out = a; *b_out = b;
+    return true;
+}
+
+struct TriHit {
+    float t, b0, b1, b2;
+    V3 n;
+};
+
+// triangle_mesh.rs:185-234 (the back-face cull needs the interpolated normal, so attrs are read here)
+RT_DEV bool tri_test(const DScene &sc, uint32_t slot, float4 q0, float p3z, float4 q2, const Ray &r, float t_min, float t_max, TriHit *h) {
+    V3 p1 = v3(q0.x, q0.y, q0.z), p2 = v3(q0.w, q2.x, q2.y), p3 = v3(q2.z, q2.w, p3z);
+    V3 e1 = p2 - p1, e2 = p3 - p1;
+    V3 s1 = cross(r.d, e2);
+    float div = dot(s1, e1);
+    if (div == 0.0f) return false;
+    float inv_div = 1.0f / div;
+    V3 d = r.o - p1;
+    float b1 = dot(d, s1) * inv_div;
+    if (b1 < 0.0f || b1 > 1.0f) return false;
+    V3 s2 = cross(d, e1);
+    float b2 = dot(r.d, s2) * inv_div;
+    if (b2 < 0.0f || (b1 + b2) > 1.0f) return false;
+    float t = dot(e2, s2) * inv_div;
+    if (t < t_min || t > t_max) return false;
+    float b0 = 1.0f - b1 - b2;
+    float4 a0 = sc.attrs[4 * (size_t)slot], a1 = sc.attrs[4 * (size_t)slot + 1], a2 = sc.attrs[4 * (size_t)slot + 2];
+    V3 n1 = v3(a0.x, a0.y, a0.z), n2 = v3(a0.w, a1.x, a1.y), n3 = v3(a1.z, a1.w, a2.x);
+    V3 n = normalize(b0 * n1 + b1 * n2 + b2 * n3);
+    if (dot(r.d, n) > 0.0f) return false;
+    h->t = t; h->b0 = b0; h->b1 = b1; h->b2 = b2; h->n = n;
+    return true;
+}
+
+// Hit test of one slot: true + t when `obj.hit(r, t_min, t_max)` of that leaf would return Some.
+template <bool STATS>
+RT_DEV bool slot_hit(const DScene &sc, uint32_t slot, const Ray &r_world, float t_min, float t_max, float *t_out, int32_t *id_out,
+                     Counters &cnt) {
+    float4 q0 = sc.slots[4 * (size_t)slot], meta = sc.slots[4 * (size_t)slot + 1];
+    int w4 = f2i(meta.x);
+    int type = w4 & 15;
+    int xf = (w4 >> 8) - 1;
+    *id_out = f2i(meta.z);
+    if (STATS) cnt.prim_tests[type] += 1;
+    Ray r = xf >= 0 ? to_object(sc, xf, r_world) : r_world;
+    float a, b;
+    switch (type) {
+    case RT_PRIM_SPHERE:
+        return sphere_roots(v3(q0.x, q0.y, q0.z), q0.w, r, t_min, t_max, t_out);
+    case RT_PRIM_MOVING_SPHERE: {
+        float4 q2 = sc.slots[4 * (size_t)slot + 2];
+        return sphere_roots(moving_center(q0, meta.w, q2, r.time), q0.w, r, t_min, t_max, t_out);
+    }
+    case RT_PRIM_XY_RECT: case RT_PRIM_XZ_RECT: case RT_PRIM_YZ_RECT:
+        return rect_test(type, q0, meta.w, r, t_min, t_max, t_out, &a, &b);
+    default: {
+        float4 q2 = sc.slots[4 * (size_t)slot + 2];
+        TriHit th;
+        if (!tri_test(sc, slot, q0, meta.w, q2, r, t_min, t_max, &th)) return false;
+        *t_out = th.t;
+        return true;
+    }
+    }
+}
+
+RT_DEV void sphere_uv(V3 p, float *u, float *v) {  // sphere.rs:25-41
+    float theta = pm::acosf_(-p.y);
+    float phi = pm::atan2f_(-p.z, p.x) + 3.14159265358979323846f;
+    *u = phi / (float)(2.0 * 3.14159265358979323846);
+    *v = theta / 3.14159265358979323846f;
+}
+
+// Full HitRecord of a slot for a known t: the same arithmetic as the leaf's hit() followed by
+// the wrappers on the way out (RotateY transform.rs:128-143, Translate :35-44, FlipFace).
+RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, float t, bool want_uv) {
+    float4 q0 = sc.slots[4 * (size_t)slot], meta = sc.slots[4 * (size_t)slot + 1];
+    int w4 = f2i(meta.x);
+    int type = w4 & 15;
+    int xf = (w4 >> 8) - 1;
+    Ray r = xf >= 0 ? to_object(sc, xf, r_world) : r_world;
+    Rec rec;
+    rec.t = t;
+    rec.material = f2i(meta.y);
+    rec.u = 0.0f; rec.v = 0.0f;
+    V3 p = r.at(t), n;
+    switch (type) {
+    case RT_PRIM_SPHERE: case RT_PRIM_MOVING_SPHERE: {
+        V3 c = v3(q0.x, q0.y, q0.z);
+        if (type == RT_PRIM_MOVING_SPHERE) c = moving_center(q0, meta.w, sc.slots[4 * (size_t)slot + 2], r.time);
+        n = (p - c) / q0.w;
+        if (want_uv) sphere_uv(n, &rec.u, &rec.v);
+        break;
+    }
+    case RT_PRIM_XY_RECT: case RT_PRIM_XZ_RECT: case RT_PRIM_YZ_RECT: {
+        int AX = type == RT_PRIM_XY_RECT ? 2 : (type == RT_PRIM_XZ_RECT ? 1 : 0);
+        int A = type == RT_PRIM_YZ_RECT ? 1 : 0;
+        int B = type == RT_PRIM_XY_RECT ? 1 : 2;
+        float a = comp(r.o, A) + t * comp(r.d, A);
+        float b = comp(r.o, B) + t * comp(r.d, B);
+        rec.u = (a - q0.x) / (q0.y - q0.x);
+        rec.v = (b - q0.z) / (q0.w - q0.z);
+        n = v3(AX == 0 ? 1.0f : 0.0f, AX == 1 ? 1.0f : 0.0f, AX == 2 ? 1.0f : 0.0f);
+        break;
+    }
+    default: {
+        float4 q2 = sc.slots[4 * (size_t)slot + 2];
+        TriHit th;
+        tri_test(sc, slot, q0, meta.w, q2, r, -RT_F32_MAX, RT_F32_MAX, &th);  // same arithmetic as the accepted test
+        n = th.n;
+        float4 a2 = sc.attrs[4 * (size_t)slot + 2], a3 = sc.attrs[4 * (size_t)slot + 3];
+        rec.u = th.b0 * a2.y + th.b1 * a2.w + th.b2 * a3.y;
+        rec.v = th.b0 * a2.z + th.b1 * a3.x + th.b2 * a3.z;
+        break;
+    }
+    }
+    bool front = dot(r.d, n) < 0.0f;  // hittable.rs:26
+    V3 nn = front ? n : -n;
+    if (xf >= 0) {
+        float4 xa = sc.xforms[2 * xf], xb = sc.xforms[2 * xf + 1];
+        int flags = f2i(xa.x);
+        if (flags & 1) {
+            float sin_t = xa.y, cos_t = xa.z;
+            V3 p0 = p, n0 = nn;
+            p.x = cos_t * p0.x + sin_t * p0.z;
+            p.z = -sin_t * p0.x + cos_t * p0.z;
+            nn.x = cos_t * n0.x + sin_t * n0.z;
+            nn.z = -sin_t * n0.x + cos_t * n0.z;
+        }
+        if (flags & 2) {
+            p = p + v3(xa.w, xb.x, xb.y);
+            front = dot(r_world.d, nn) < 0.0f;  // transform.rs:36: HitRecord::new again (direction is unchanged by Translate)
+            nn = front ? nn : -nn;
+        }
+    }
+    if (w4 & 16) front = !front;  // flip_face.rs:24-27
+    rec.p = p; rec.normal = nn; rec.front_face = front;
+    return rec;
+}
+
+/* ------------------------------------------------------------------ closest hit */
+
+// HittableList::hit fold (hittable_list.rs:43-49) for candidates that may arrive in any order:
+// smaller t wins, equal t -> later object (larger primitive id).  A NaN t never wins here; rays
+// that can produce NaN go through closest_hit_exhaustive().
+RT_DEV void consider(Hit &best, float t, int32_t id, int32_t slot) {
+    if (t < best.t || (t == best.t && id > best.id)) { best.t = t; best.id = id; best.slot = slot; }
+}
+
+// Slab test in the traversal's own arithmetic (boxes are padded by the flattener, so this need
+// not follow aabb3.rs).  NaNs from 0*inf are ignored by fminf/fmaxf, which keeps it conservative.
+RT_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv, float t_min, float t_max, float *t_near) {
+    float tx0 = (lo.x - o.x) * inv.x, tx1 = (hi.x - o.x) * inv.x;
+    float ty0 = (lo.y - o.y) * inv.y, ty1 = (hi.y - o.y) * inv.y;
+    float tz0 = (lo.z - o.z) * inv.z, tz1 = (hi.z - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t_max));
+    *t_near = tn;
+    return tn <= tf * 1.0000004f;
+}
+
+template <bool STATS>
+RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, Hit &best, uint2 *stack, uint32_t stride, Counters &cnt) {
+    int32_t ref = sc.root_ref;
+    if (ref == RT_BVH_EMPTY) return;
+    V3 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    uint32_t sp = 0;
+    for (;;) {
+        if (ref >= 0) {
+            const float4 *n = sc.nodes + 4 * (size_t)ref;
+            float4 a = n[0], b = n[1], c = n[2], d = n[3];
+            if (STATS) cnt.node_visits += 1;
+            float tl, tr;
+            bool hl = slab(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), r.o, inv, t_min, best.t, &tl);
+            bool hr = slab(v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), r.o, inv, t_min, best.t, &tr);
+            int32_t rl = f2i(d.x), rr = f2i(d.y);
+            if (hl && hr) {
+                bool left_first = tl <= tr;
+                int32_t far_ref = left_first ? rr : rl;
+                float far_t = left_first ? tr : tl;
+                stack[sp * stride] = make_uint2((uint32_t)far_ref, __float_as_uint(far_t));
+                ++sp;
+                ref = left_first ? rl : rr;
+                continue;
+            }
+            if (hl) { ref = rl; continue; }
+            if (hr) { ref = rr; continue; }
+        } else {
+            uint32_t code = (uint32_t)~ref;
+            uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                float t;
+                int32_t id;
+                if (slot_hit<STATS>(sc, first + i, r, t_min, best.t, &t, &id, cnt)) consider(best, t, id, (int32_t)(first + i));
+            }
+        }
+        // pop; entries whose box starts beyond the current best cannot contain a closer-or-equal hit
+        for (;;) {
+            if (sp == 0) return;
+            --sp;
+            uint2 e = stack[sp * stride];
+            if (__uint_as_float(e.y) <= best.t) { ref = (int32_t)e.x; break; }
+        }
+    }
+}
+
+// ConstantMedium::hit (constant_medium.rs:46-94) for a sphere boundary.  Draws random_real()
+// exactly when the reference does.
+template <bool STATS>
+RT_DEV bool medium_hit(const DScene &sc, uint32_t m, const Ray &r, float t_min, float t_max, rts::Rng &rng, float *t_out, Counters &cnt) {
+    float4 a = sc.media[2 * m], b = sc.media[2 * m + 1];
+    if (STATS) cnt.medium_tests += 1;
+    V3 c = v3(a.x, a.y, a.z);
+    float t1, t2;
+    if (!sphere_roots(c, a.w, r, -RT_F32_MAX, RT_F32_MAX, &t1)) return false;
+    if (!sphere_roots(c, a.w, r, t1 + 0.0001f, RT_F32_MAX, &t2)) return false;
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return false;
+    if (t1 < 0.0f) t1 = 0.0f;
+    float ray_length = length(r.d);
+    float distance_inside = (t2 - t1) * ray_length;
+    float hit_distance = b.x * pm::logf_(rts::random_real(rng));
+    if (hit_distance > distance_inside) return false;
+    *t_out = t1 + hit_distance / ray_length;
+    return true;
+}
+
+RT_DEV bool finite_f(float x) { return fabsf(x) < INFINITY; }
+
+// Rays the BVH cannot serve with reference semantics: a non-finite or zero direction component
+// (NaN hit distances are ACCEPTED by the reference's comparisons, sphere.rs:61-65,
+// rectangles.rs:25-32, and the list fold then keeps the last such object), or a non-finite origin.
+RT_DEV bool ray_is_regular(const Ray &r) {
+    return finite_f(r.o.x) && finite_f(r.o.y) && finite_f(r.o.z) && finite_f(r.d.x) && finite_f(r.d.y) && finite_f(r.d.z) &&
+           r.d.x != 0.0f && r.d.y != 0.0f && r.d.z != 0.0f && finite_f(r.time);
+}
+
+// The reference's fold, literally: candidates in list order, `best` replaced unless best.t < t.
+// Because slots are not stored in list order this runs as two passes over all slots: the fold's
+// result is the minimum (ties -> later) over the candidates that come after the last candidate
+// with an unordered (NaN) t, or that NaN candidate itself if it is the last one.
+template <bool STATS>
+RT_DEV void closest_hit_exhaustive(const DScene &sc, const Ray &r, float t_min, float t_max, const float *med_t, const bool *med_ok,
+                                   Hit &best, Counters &cnt) {
+    int32_t last_nan_id = -1, last_nan_slot = 0;
+    int32_t last_id = -1;
+    for (uint32_t s = 0; s < sc.n_slots; ++s) {
+        float t; int32_t id;
+        if (!slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt)) continue;
+        if (id > last_id) last_id = id;
+        if (t != t && id > last_nan_id) { last_nan_id = id; last_nan_slot = (int32_t)s; }
+    }
+    for (uint32_t m = 0; m < sc.n_media; ++m) {
+        if (!med_ok[m]) continue;
+        int32_t id = f2i(sc.media[2 * m + 1].z);
+        if (id > last_id) last_id = id;
+        if (med_t[m] != med_t[m] && id > last_nan_id) { last_nan_id = id; last_nan_slot = -(int32_t)(m + 1); }
+    }
+    best.t = INFINITY; best.id = -1; best.slot = 0;
+    if (last_id < 0) return;
+    if (last_nan_id == last_id) { best.t = __int_as_float(0x7fc00000); best.id = last_nan_id; best.slot = last_nan_slot; return; }
+    bool any = false;
+    for (uint32_t s = 0; s < sc.n_slots; ++s) {
+        float t; int32_t id;
+        if (!slot_hit<false>(sc, s, r, t_min, t_max, &t, &id, cnt)) continue;
+        if (id <= last_nan_id) continue;
+        if (!any || t < best.t || (t == best.t && id > best.id)) { best.t = t; best.id = id; best.slot = (int32_t)s; any = true; }
+    }
+    for (uint32_t m = 0; m < sc.n_media; ++m) {
+        if (!med_ok[m]) continue;
+        int32_t id = f2i(sc.media[2 * m + 1].z);
+        if (id <= last_nan_id) continue;
+        float t = med_t[m];
+        if (!any || t < best.t || (t == best.t && id > best.id)) { best.t = t; best.id = id; best.slot = -(int32_t)(m + 1); any = true; }
+    }
+}
+
+// world.hit(r, t_min, t_max): surfaces through the BVH, media in list order (they draw random
+// numbers), everything folded with list semantics.  `with_media` = false for the parity hook.
+template <bool STATS>
+RT_DEV bool closest_hit(const DScene &sc, const Ray &r, float t_min, float t_max, bool with_media, rts::Rng &rng, Hit &best,
+                        uint2 *stack, uint32_t stride, Counters &cnt) {
+    float med_t[RT_MAX_MEDIA];
+    bool med_ok[RT_MAX_MEDIA];
+#pragma unroll
+    for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m) {
+        med_ok[m] = false; med_t[m] = 0.0f;
+        if (with_media && m < sc.n_media) med_ok[m] = medium_hit<STATS>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
+    }
+    if (!ray_is_regular(r)) {
+        closest_hit_exhaustive<STATS>(sc, r, t_min, t_max, med_t, med_ok, best, cnt);
+        return best.id >= 0;
+    }
+    best.t = t_max; best.id = -1; best.slot = 0;
+    bool any = false;
+    // t == t_max is accepted by every leaf (e.g. `t > t_max` rejects, rectangles.rs:25), so the
+    // first candidate must win even at t == t_max: start below any id.
+    for (uint32_t i = 0; i < sc.always_count; ++i) {
+        float t; int32_t id;
+        uint32_t s = sc.always_begin + i;
+        if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt)) consider(best, t, id, (int32_t)s);
+    }
+    traverse<STATS>(sc, r, t_min, best, stack, stride, cnt);
+    // MovingSphere boxes cover the shutter interval only; isotropic.rs:32 can hand a ray any "time"
+    if (sc.n_moving && !(r.time >= 0.0f && r.time <= 1.0f))
+        for (uint32_t i = 0; i < sc.n_moving; ++i) {
+            float t; int32_t id;
+            uint32_t s = sc.moving[i];
+            if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt)) consider(best, t, id, (int32_t)s);
+        }
+#pragma unroll
+    for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m)
+        if (med_ok[m]) consider(best, med_t[m], f2i(sc.media[2 * m + 1].z), -(int32_t)(m + 1));
+    any = best.id >= 0;
+    return any;
+}
+
+/* ------------------------------------------------------------------ textures */
+
+RT_DEV float perlin_smooth(float t) { return t * t * (3.0f - 2.0f * t); }  // perlin.rs:60-62
+
+RT_DEV float perlin_noise(const uint32_t *tab, V3 p) {  // perlin.rs:84-108 + 38-58
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = perlin_smooth(p.x - fx), v = perlin_smooth(p.y - fy), w = perlin_smooth(p.z - fz);
+    int i = pm::f2i_sat(fx), j = pm::f2i_sat(fy), k = pm::f2i_sat(fz);
+    float uu = perlin_smooth(u), vv = perlin_smooth(v), ww = perlin_smooth(w);
+    float accum = 0.0f;
+    for (int di = 0; di < 2; ++di)
+        for (int dj = 0; dj < 2; ++dj)
+            for (int dk = 0; dk < 2; ++dk) {
+                uint32_t idx = tab[768 + ((uint32_t)(i + di) & 255u)] ^ tab[1024 + ((uint32_t)(j + dj) & 255u)] ^
+                               tab[1280 + ((uint32_t)(k + dk) & 255u)];
+                V3 c = v3(__uint_as_float(tab[3 * idx]), __uint_as_float(tab[3 * idx + 1]), __uint_as_float(tab[3 * idx + 2]));
+                V3 weight = v3(u - (float)di, v - (float)dj, w - (float)dk);
+                accum += ((float)di * uu + (1.0f - (float)di) * (1.0f - uu)) * ((float)dj * vv + (1.0f - (float)dj) * (1.0f - vv)) *
+                         ((float)dk * ww + (1.0f - (float)dk) * (1.0f - ww)) * dot(c, weight);
+            }
+    return accum;
+}
+
+RT_DEV float perlin_turbulence(const uint32_t *tab, V3 p, int depth) {  // perlin.rs:110-123
+    V3 temp_p = p;
+    float weight = 1.0f, acc = 0.0f;
+    for (int d = 0; d < depth; ++d) {
+        acc = acc + weight * perlin_noise(tab, temp_p);
+        weight *= 0.5f;
+        temp_p = temp_p * 2.0f;
+    }
+    return fabsf(acc);
+}
+
+RT_DEV bool texture_needs_uv(const DScene &sc, int tex) {
+    for (int level = 0; level < 8; ++level) {
+        int type = f2i(sc.textures[2 * tex].x);
+        if (type == RTG_TEX_IMAGE) return true;
+        if (type != RTG_TEX_CHECKER) return false;
+        float4 b = sc.textures[2 * tex + 1];
+        // either branch may be an image; be conservative
+        int odd = f2i(b.x), even = f2i(b.y);
+        if (f2i(sc.textures[2 * odd].x) == RTG_TEX_IMAGE || f2i(sc.textures[2 * even].x) == RTG_TEX_IMAGE) return true;
+        tex = even;
+    }
+    return true;
+}
+
+template <bool STATS>
+RT_DEV V3 texture_value(const DScene &sc, int tex, float u, float v, V3 p, Counters &cnt) {
+    for (int level = 0; level < 16; ++level) {
+        float4 a = sc.textures[2 * tex], b = sc.textures[2 * tex + 1];
+        int type = f2i(a.x);
+        if (STATS) cnt.tex_evals[type & 3] += 1;
+        if (type == RTG_TEX_SOLID) return v3(a.y, a.z, a.w);
+        if (type == RTG_TEX_CHECKER) {  // checker_texture.rs:37-45
+            float f = b.z;
+            float sines = pm::sinf_(f * p.x) * pm::sinf_(f * p.y) * pm::sinf_(f * p.z);
+            tex = sines < 0.0f ? f2i(b.x) : f2i(b.y);
+            continue;
+        }
+        if (type == RTG_TEX_NOISE) {  // noise_texture.rs:28-30
+            const uint32_t *tab = sc.perlin + (size_t)f2i(b.x) * RT_PERLIN_WORDS;
+            float k = 1.0f + pm::sinf_(b.z * p.z + 10.0f * perlin_turbulence(tab, p, 7));
+            float g = 1.0f * 0.5f;
+            return v3(g * k, g * k, g * k);
+        }
+        // image_texture.rs:50-86
+        int off = f2i(b.x);
+        if (off < 0) return v3(0.0f, 1.0f, 1.0f);
+        int width = f2i(b.y), height = f2i(b.w);
+        float uc = f32_clamp(u, 0.0f, 1.0f);
+        float vc = 1.0f - f32_clamp(v, 0.0f, 1.0f);
+        int i = pm::f2i_sat(uc * (float)width), j = pm::f2i_sat(vc * (float)height);
+        if (i >= width) i = width - 1;
+        if (j >= height) j = height - 1;
+        uint32_t px = sc.texels[(size_t)off + (size_t)j * (size_t)width + (size_t)i];
+        float scale = 1.0f / 255.0f;
+        return v3(scale * (float)(px & 255u), scale * (float)((px >> 8) & 255u), scale * (float)((px >> 16) & 255u));
+    }
+    return v3(0.0f, 0.0f, 0.0f);
+}
+
+/* ------------------------------------------------------------------ pdfs */
+
+struct Onb {
+    V3 u, v, w;
+};
+RT_DEV Onb onb_from(V3 n) {  // onb.rs:32-47
+    Onb o;
+    o.w = normalize(n);
+    V3 a = fabsf(o.w.x) > 0.9f ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f);
+    o.v = normalize(cross(o.w, a));
+    o.u = cross(o.w, o.v);
+    return o;
+}
+RT_DEV V3 onb_local(const Onb &o, V3 a) { return a.x * o.u + a.y * o.v + a.z * o.w; }
+
+RT_DEV V3 random_in_unit_sphere(rts::Rng &rng) {  // types.rs:95-104
+    for (;;) {
+        float x = rts::random_real_range(rng, -1.0f, 1.0f);
+        float y = rts::random_real_range(rng, -1.0f, 1.0f);
+        float z = rts::random_real_range(rng, -1.0f, 1.0f);
+        V3 p = v3(x, y, z);
+        if (length_squared(p) >= 1.0f) continue;
+        return p;
+    }
+}
+
+RT_DEV V3 random_cosine_direction(rts::Rng &rng) {  // types.rs:141-151
+    float r1 = rts::random_real(rng), r2 = rts::random_real(rng);
+    float z = sqrtf(1.0f - r2);
+    float phi = (float)(2.0 * 3.14159265358979323846) * r1;
+    float s, c;
+    pm::sincosf_(phi, &s, &c);
+    float sr = sqrtf(r2);
+    return v3(c * sr, s * sr, z);
+}
+
+RT_DEV V3 random_to_sphere(rts::Rng &rng, float radius, float distance_squared) {  // types.rs:153-163
+    float r1 = rts::random_real(rng), r2 = rts::random_real(rng);
+    float z = 1.0f + r2 * (sqrtf(1.0f - radius * radius / distance_squared) - 1.0f);
+    float phi = (float)(2.0 * 3.14159265358979323846) * r1;
+    float s, c;
+    pm::sincosf_(phi, &s, &c);
+    float k = sqrtf(1.0f - z * z);
+    return v3(c * k, s * k, z);
+}
+
+// lights.random(origin): hittable_list.rs:71-75 then the object's random()
+RT_DEV V3 lights_random(const DScene &sc, V3 origin, rts::Rng &rng) {
+    int idx = rts::random_int(rng, 0, (int)sc.n_lights - 1);
+    float4 a = sc.lights[2 * idx], b = sc.lights[2 * idx + 1];
+    int type = f2i(a.x);
+    if (type == RT_PRIM_SPHERE) {  // sphere.rs:107-112
+        V3 direction = v3(a.y, a.z, a.w) - origin;
+        float distance_squared = length_squared(direction);
+        Onb uvw = onb_from(direction);
+        return onb_local(uvw, random_to_sphere(rng, b.x, distance_squared));
+    }
+    if (type == 255) return v3(1.0f, 0.0f, 0.0f);  // hittable.rs:51-53
+    // rectangles.rs:69-77 / 139-147 / 209-217: a0,a1,b0,b1,k = a.y a.z a.w b.x b.y
+    float ra = rts::random_real_range(rng, a.y, a.z);
+    float rb = rts::random_real_range(rng, a.w, b.x);
+    V3 pt = type == RT_PRIM_XY_RECT ? v3(ra, rb, b.y) : (type == RT_PRIM_XZ_RECT ? v3(ra, b.y, rb) : v3(b.y, ra, rb));
+    return pt - origin;
+}
+
+// lights.pdf_value(origin, v): hittable_list.rs:59-69
+template <bool STATS>
+RT_DEV float lights_pdf_value(const DScene &sc, V3 origin, V3 v, Counters &cnt) {
+    if (sc.n_lights == 0) return 0.0f;
+    float weight = 1.0f / (float)sc.n_lights;
+    float sum = 0.0f;
+    Ray r{origin, v, 0.0f};
+    for (uint32_t i = 0; i < sc.n_lights; ++i) {
+        float4 a = sc.lights[2 * i], b = sc.lights[2 * i + 1];
+        int type = f2i(a.x);
+        float val = 0.0f;
+        if (STATS) cnt.light_pdf_evals += 1;
+        if (type == RT_PRIM_SPHERE) {  // sphere.rs:91-105
+            float t;
+            V3 c = v3(a.y, a.z, a.w);
+            if (sphere_roots(c, b.x, r, 0.001f, RT_F32_MAX, &t)) {
+                float cos_theta_max = sqrtf(1.0f - b.x * b.x / length_squared(c - origin));
+                float solid_angle = 2.0f * 3.14159265358979323846f * (1.0f - cos_theta_max);
+                val = 1.0f / solid_angle;
+            }
+        } else if (type != 255) {  // rectangles.rs:54-67
+            float t, pa, pb;
+            float4 q0 = make_float4(a.y, a.z, a.w, b.x);
+            if (rect_test(type, q0, b.y, r, 0.001f, RT_F32_MAX, &t, &pa, &pb)) {
+                int AX = type == RT_PRIM_XY_RECT ? 2 : (type == RT_PRIM_XZ_RECT ? 1 : 0);
+                V3 n = v3(AX == 0 ? 1.0f : 0.0f, AX == 1 ? 1.0f : 0.0f, AX == 2 ? 1.0f : 0.0f);
+                bool front = dot(v, n) < 0.0f;
+                V3 nn = front ? n : -n;
+                float area = (q0.y - q0.x) * (q0.w - q0.z);
+                float distance_squared = t * t * length_squared(v);
+                float cosine = fabsf(dot(v, nn) / length(v));
+                val = distance_squared / (cosine * area);
+            }
+        }
+        sum = sum + weight * val;
+    }
+    return sum;
+}
+
+RT_DEV float powi5(float a) {
+    float a2 = a * a, a4 = a2 * a2;
+    return a * a4;
+}
+RT_DEV float schlick(float cosine, float ior) {  // types.rs:165-169
+    float r0 = (1.0f - ior) / (1.0f + ior);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * powi5(1.0f - cosine);
+}
+
+/* ------------------------------------------------------------------ one bounce of ray_color */
+
+struct Path {
+    Ray ray;
+    V3 throughput;   // product of the weights so far
+    V3 radiance;     // sum of throughput * emitted
+    int depth;       // remaining depth (camera.rs:258)
+};
+
+// Returns true while the path continues.  camera.rs:253-309.
+template <bool STATS>
+RT_DEV bool bounce(const DScene &sc, Path &ps, V3 background, rts::Rng &rng, uint2 *stack, uint32_t stride, Counters &cnt) {
+    if (ps.depth <= 0) return false;  // contributes 0
+    if (STATS) cnt.rays += 1;
+    Hit best;
+    if (!closest_hit<STATS>(sc, ps.ray, 0.001f, INFINITY, true, rng, best, stack, stride, cnt)) {
+        ps.radiance = ps.radiance + ps.throughput * background;
+        return false;
+    }
+    if (STATS) cnt.accepted += 1;
+    Rec rec;
+    if (best.slot < 0) {  // ConstantMedium record (constant_medium.rs:85-93)
+        uint32_t m = (uint32_t)(-best.slot - 1);
+        float4 mb = sc.media[2 * m + 1];
+        rec.t = best.t;
+        rec.p = ps.ray.at(best.t);
+        rec.normal = v3(1.0f, 0.0f, 0.0f);
+        rec.front_face = true;
+        rec.material = f2i(mb.y);
+        rec.u = 0.0f; rec.v = 0.0f;
+        int tex = f2i(sc.materials[2 * rec.material].y);
+        if (texture_needs_uv(sc, tex)) {  // u,v of the boundary's first hit
+            float4 ma = sc.media[2 * m];
+            float t1;
+            V3 c = v3(ma.x, ma.y, ma.z);
+            if (sphere_roots(c, ma.w, ps.ray, -RT_F32_MAX, RT_F32_MAX, &t1)) sphere_uv((ps.ray.at(t1) - c) / ma.w, &rec.u, &rec.v);
+        }
+    } else {
+        int mat = f2i(sc.slots[4 * (size_t)best.slot + 1].y);
+        float4 ma = sc.materials[2 * mat];
+        int mtype = f2i(ma.x);
+        bool want_uv = (mtype == RTG_MAT_LAMBERTIAN || mtype == RTG_MAT_DIFFUSE_LIGHT || mtype == RTG_MAT_ISOTROPIC) &&
+                       texture_needs_uv(sc, f2i(ma.y));
+        rec = slot_record(sc, (uint32_t)best.slot, ps.ray, best.t, want_uv);
+    }
+    float4 ma = sc.materials[2 * rec.material], mb = sc.materials[2 * rec.material + 1];
+    int mtype = f2i(ma.x);
+    if (STATS) cnt.shades[mtype < 5 ? mtype : 4] += 1;
+    const Ray &r = ps.ray;
+    switch (mtype) {
+    case RTG_MAT_DIFFUSE_LIGHT: {  // diffuse_light.rs:43-56; scatter = None -> return emitted
+        if (rec.front_face) {
+            V3 e = texture_value<STATS>(sc, f2i(ma.y), rec.u, rec.v, rec.p, cnt);
+            ps.radiance = ps.radiance + ps.throughput * e;
+        }
+        return false;
+    }
+    case RTG_MAT_METAL: {  // metal.rs:21-36
+        V3 reflected = reflect_unit_vector(r.d, normalize(rec.normal));
+        V3 scattered = reflected + mb.y * random_in_unit_sphere(rng);
+        if (!(dot(scattered, rec.normal) > 0.0f)) return false;  // None -> emitted = 0
+        ps.throughput = ps.throughput * v3(ma.z, ma.w, mb.x);
+        ps.ray = Ray{rec.p, scattered, r.time};
+        break;
+    }
+    case RTG_MAT_DIELECTRIC: {  // dielectric.rs:17-67
+        float ior = mb.z;
+        float eta = rec.front_face ? 1.0f / ior : ior;
+        V3 uv = normalize(r.d);
+        float cos_theta = f32_min(dot(-uv, rec.normal), 1.0f);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        V3 dir;
+        if (eta * sin_theta > 1.0f) {
+            dir = reflect_unit_vector(uv, normalize(rec.normal));
+        } else {
+            float reflect_probability = schlick(cos_theta, eta);
+            if (rts::random_real(rng) < reflect_probability) dir = reflect_unit_vector(uv, rec.normal);
+            else dir = refract(uv, rec.normal, eta);
+        }
+        ps.throughput = ps.throughput * v3(1.0f, 1.0f, 1.0f);
+        ps.ray = Ray{rec.p, dir, r.time};
+        break;
+    }
+    case RTG_MAT_ISOTROPIC: {  // isotropic.rs:26-35
+        V3 dir = random_in_unit_sphere(rng);
+        V3 att = texture_value<STATS>(sc, f2i(ma.y), rec.u, rec.v, rec.p, cnt);
+        ps.throughput = ps.throughput * att;
+        ps.ray = Ray{rec.p, dir, rec.t};  // sic: time = hit t
+        break;
+    }
+    default: {  // Lambertian: lambertian.rs:33-51 + camera.rs:271-301
+        V3 albedo = texture_value<STATS>(sc, f2i(ma.y), rec.u, rec.v, rec.p, cnt);
+        Onb uvw = onb_from(rec.normal);
+        V3 dir;
+        if (rts::random_real(rng) < 0.5f) dir = lights_random(sc, rec.p, rng);
+        else dir = onb_local(uvw, random_cosine_direction(rng));
+        // MixturePdf::value (pdf.rs:68-70)
+        float light_val = lights_pdf_value<STATS>(sc, rec.p, dir, cnt);
+        float cosine = dot(normalize(dir), uvw.w);
+        float cos_val = cosine <= 0.0f ? 0.0f : cosine * (float)0.318309886183790671537767526745028724;
+        float pdf_val = 0.5f * light_val + 0.5f * cos_val;
+        if (fabsf(pdf_val) < 1.0E-5f) pdf_val = (__float_as_uint(pdf_val) >> 31) ? -1.0E-4f : 1.0E-4f;
+        float sc_cos = dot(rec.normal, normalize(dir));
+        float spdf = sc_cos < 0.0f ? 0.0f : sc_cos / 3.14159265358979323846f;
+        ps.throughput = ps.throughput * ((albedo * spdf) / pdf_val);
+        ps.ray = Ray{rec.p, dir, r.time};
+        break;
+    }
+    }
+    ps.depth -= 1;
+    return true;
+}
+
+/* ------------------------------------------------------------------ kernels */
+
+struct RenderArgs {
+    int32_t width, height, spp, spp_begin, spp_count, max_depth;
+    float bg[3];
+    uint32_t seed;
+    int32_t x0, y0, x1, y1;
+    rt_camera cam;
+};
+
+// camera.rs:196-198 + 82-96
+RT_DEV Ray camera_ray(const DScene &sc, const RenderArgs &a, int x, int y, uint32_t pixel, uint32_t s, rts::Rng &rng) {
+    uint32_t i0 = rts::sampler_index(a.seed, pixel, 2u * s, sc.sets, sc.spp, sc.shuffled);
+    float2 off = sc.samples[i0];
+    float u = ((float)x + off.x) / (float)(a.width - 1);
+    float v = 1.0f - ((float)y + off.y) / (float)(a.height - 1);
+    uint32_t i1 = rts::sampler_index(a.seed, pixel, 2u * s + 1u, sc.sets, sc.spp, sc.shuffled);
+    float2 dk = sc.disk[i1];
+    float rdx = a.cam.lens_radius * dk.x, rdy = a.cam.lens_radius * dk.y;
+    V3 cu = v3(a.cam.u[0], a.cam.u[1], a.cam.u[2]), cv = v3(a.cam.v[0], a.cam.v[1], a.cam.v[2]);
+    V3 origin = v3(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
+    V3 llc = v3(a.cam.lower_left_corner[0], a.cam.lower_left_corner[1], a.cam.lower_left_corner[2]);
+    V3 hor = v3(a.cam.horizontal[0], a.cam.horizontal[1], a.cam.horizontal[2]);
+    V3 ver = v3(a.cam.vertical[0], a.cam.vertical[1], a.cam.vertical[2]);
+    V3 offset = cu * rdx + cv * rdy;
+    Ray r;
+    r.o = origin + offset;
+    r.d = llc + u * hor + v * ver - origin - offset;
+    r.time = rts::random_real(rng);
+    return r;
+}
+
+RT_DEV uint32_t wave_sum(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Block = 256 lanes = 2x2 wave tiles of 8x8 pixels.  Dynamic LDS = stack_depth * 256 * 8 bytes.
+template <bool STATS>
+__global__ void __launch_bounds__(256) render_kernel(DScene sc, RenderArgs a, float4 *__restrict__ out, unsigned long long *stats,
+                                                     uint32_t *pixel_rays) {
+    extern __shared__ uint2 lds_stack[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    const int tiles_x = (a.x1 - a.x0 + 15) / 16;
+    const int bx = (int)(blockIdx.x % (uint32_t)tiles_x), by = (int)(blockIdx.x / (uint32_t)tiles_x);
+    const int x = a.x0 + bx * 16 + (int)(wave & 1u) * 8 + (int)(lane & 7u);
+    const int y = a.y0 + by * 16 + (int)(wave >> 1) * 8 + (int)(lane >> 3);
+    uint2 *stack = lds_stack + tid;
+    const uint32_t stride = blockDim.x;
+    Counters cnt{};
+    bool inside = x < a.x1 && y < a.y1;
+    if (inside) {
+        const uint32_t pixel = (uint32_t)y * (uint32_t)a.width + (uint32_t)x;
+        const V3 background = v3(a.bg[0], a.bg[1], a.bg[2]);
+        V3 sum = v3(0.0f, 0.0f, 0.0f);
+        int s = a.spp_begin;
+        const int s_end = a.spp_begin + a.spp_count;
+        bool alive = false;
+        Path ps;
+        rts::Rng rng;
+        for (;;) {
+            if (!alive) {
+                if (s >= s_end) break;
+                rts::path_rng(rng, a.seed, pixel, (uint32_t)s);
+                ps.ray = camera_ray(sc, a, x, y, pixel, (uint32_t)s, rng);
+                ps.throughput = v3(1.0f, 1.0f, 1.0f);
+                ps.radiance = v3(0.0f, 0.0f, 0.0f);
+                ps.depth = a.max_depth;
+                ++s;
+                alive = true;
+            }
+            alive = bounce<STATS>(sc, ps, background, rng, stack, stride, cnt);
+            if (!alive) sum = sum + ps.radiance;  // camera.rs:203: color + ray_color(...)
+        }
+        float4 o = out[pixel];
+        o.x += sum.x; o.y += sum.y; o.z += sum.z; o.w += (float)a.spp_count;
+        out[pixel] = o;
+        if (STATS && pixel_rays) pixel_rays[pixel] += cnt.rays;
+    }
+    if (STATS) {
+        uint32_t vals[21];
+        vals[0] = inside ? (uint32_t)a.spp_count : 0u;
+        vals[1] = cnt.rays; vals[2] = cnt.node_visits;
+        for (int i = 0; i < 6; ++i) vals[3 + i] = cnt.prim_tests[i];
+        vals[9] = cnt.medium_tests; vals[10] = cnt.light_pdf_evals;
+        for (int i = 0; i < 5; ++i) vals[11 + i] = cnt.shades[i];
+        for (int i = 0; i < 4; ++i) vals[16 + i] = cnt.tex_evals[i];
+        vals[20] = cnt.accepted;
+        for (int i = 0; i < 21; ++i) {
+            uint32_t w = wave_sum(vals[i]);
+            if (lane == 0 && w) atomicAdd(&stats[i], (unsigned long long)w);
+        }
+    }
+}
+
+// Parity hook: world.hit without media for caller-supplied rays (rt_trace_first_hit).
+__global__ void __launch_bounds__(256) first_hit_kernel(DScene sc, const float *__restrict__ rays, int n, float t_min, float t_max,
+                                                        uint32_t *prim_id, float *t_out, float *normal3, uint8_t *front_face, float *uv2) {
+    extern __shared__ uint2 lds_stack[];
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    Ray r;
+    r.o = v3(rays[i], rays[(size_t)n + i], rays[2 * (size_t)n + i]);
+    r.d = v3(rays[3 * (size_t)n + i], rays[4 * (size_t)n + i], rays[5 * (size_t)n + i]);
+    r.time = rays[6 * (size_t)n + i];
+    Counters cnt{};
+    rts::Rng rng{0, 1};
+    Hit best;
+    bool h = closest_hit<false>(sc, r, t_min, t_max, false, rng, best, lds_stack + threadIdx.x, blockDim.x, cnt);
+    Rec rec{};
+    if (h) rec = slot_record(sc, (uint32_t)best.slot, r, best.t, true);
+    prim_id[i] = h ? (uint32_t)best.id : RT_MISS;
+    t_out[i] = h ? rec.t : 0.0f;
+    normal3[3 * i] = h ? rec.normal.x : 0.0f; normal3[3 * i + 1] = h ? rec.normal.y : 0.0f; normal3[3 * i + 2] = h ? rec.normal.z : 0.0f;
+    front_face[i] = h && rec.front_face ? 1 : 0;
+    if (uv2) { uv2[2 * i] = h ? rec.u : 0.0f; uv2[2 * i + 1] = h ? rec.v : 0.0f; }
+}
+
+// main.rs:1363-1388
+__global__ void __launch_bounds__(256) resolve_kernel(const float4 *__restrict__ sum, int n, float inv_spp, float4 *__restrict__ out) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    float4 s = sum[i], o;
+    o.x = !pm::is_normal_(s.x) ? 0.0f : f32_clamp(sqrtf(s.x * inv_spp), 0.0f, 1.0f);
+    o.y = !pm::is_normal_(s.y) ? 0.0f : f32_clamp(sqrtf(s.y * inv_spp), 0.0f, 1.0f);
+    o.z = !pm::is_normal_(s.z) ? 0.0f : f32_clamp(sqrtf(s.z * inv_spp), 0.0f, 1.0f);
+    o.w = s.w;
+    out[i] = o;
+}
+
+}  // namespace rtk
+#endif
