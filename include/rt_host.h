@@ -130,6 +130,11 @@ int  rth_flatten(const rtg_graph *g, rth_flat **out);
 void rth_flat_free(rth_flat *f);
 void rth_flat_desc(const rth_flat *f, rt_scene_desc *out);
 
+/* math/src/mat4.rs:512-531 and :608-617, exposed for the reference's own known-answer test
+ * (math/src/mat4.rs:641-655).  Row-major 4x4.  rth_mat4_invert returns RT_E_INVALID for det == 0. */
+void rth_mat4_mul(const float a[16], const float b[16], float out[16]);
+int  rth_mat4_invert(const float m[16], float out[16]);
+
 /* WorkBlock list of main.rs:1265-1282 (no shuffle): writes up to cap entries of x0,x1,y0,y1
  * and returns the number of blocks. */
 int32_t rth_work_blocks(int32_t width, int32_t height, int32_t block_pixels, int32_t *out_xyxy, int32_t cap);

@@ -159,7 +159,7 @@ HOST_SYMBOLS = [
     "rth_geometry_free", "rth_geometry_view", "rth_build_scene", "rth_config_load", "rth_config_parse",
     "rth_config_free", "rth_config_active_scene", "rth_config_scene_params", "rth_image_height", "rth_camera_new",
     "rth_sampler_new", "rth_sampler_free", "rth_sampler_desc", "rth_flatten", "rth_flat_free", "rth_flat_desc",
-    "rth_work_blocks",
+    "rth_work_blocks", "rth_mat4_mul", "rth_mat4_invert",
 ]
 
 HIP_SYMBOLS = [
@@ -229,6 +229,8 @@ def host_lib():
     L.rth_flat_free.argtypes = [vp]
     L.rth_flat_desc.argtypes = [vp, C.POINTER(rt_scene_desc)]; L.rth_flat_desc.restype = None
     L.rth_work_blocks.argtypes = [i32, i32, i32, C.POINTER(i32), i32]
+    L.rth_mat4_mul.argtypes = [C.c_float * 16, C.c_float * 16, C.c_float * 16]; L.rth_mat4_mul.restype = None
+    L.rth_mat4_invert.argtypes = [C.c_float * 16, C.c_float * 16]
     _host = L
     return L
 

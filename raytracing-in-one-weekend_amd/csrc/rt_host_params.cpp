@@ -3,6 +3,7 @@
 // Restates raytracer/src/main.rs:1135-1216 + :1241-1282 (config structs, load_config, scene
 // lookup, image_height, work blocks), camera.rs:39-80 (Camera::new) and sampling.rs:30-135,
 // 233-253 (SamplerBase::new over the multi-jittered strategy).
+#include <algorithm>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -406,6 +407,24 @@ void rth_sampler_desc(const rth_sampler *s, rt_sampler_desc *out) {
     out->samples = s->samples.data();
     out->disk_samples = s->disk.data();
     out->shuffled_indices = s->shuffled.data();
+}
+
+/* ------------------------------------------------------------------ math hooks */
+
+void rth_mat4_mul(const float a[16], const float b[16], float out[16]) {
+    M4 x, y;
+    memcpy(x.a, a, 64);
+    memcpy(y.a, b, 64);
+    M4 r = m4_mul(x, y);
+    memcpy(out, r.a, 64);
+}
+
+int rth_mat4_invert(const float m[16], float out[16]) {
+    M4 x, r;
+    memcpy(x.a, m, 64);
+    if (!m4_invert(x, &r)) { set_error("Matrix is not invertible"); return RT_E_INVALID; }
+    memcpy(out, r.a, 64);
+    return RT_OK;
 }
 
 /* ------------------------------------------------------------------ work blocks */

@@ -78,9 +78,11 @@ def compare_images(rt, gpu, oracle, params, camera, sampler, **kw):
     return g_img, c_img, stats
 
 
-@pytest.mark.parametrize("name,width,spp,n_rays", [("C1", 240, 9, 1 << 16), ("C2", 96, 16, 1 << 16)])
+@pytest.mark.parametrize("name,width,spp,n_rays", [("C1", 240, 9, 1 << 16), ("C2", 96, 16, 1 << 16), ("C3", 96, 16, 1 << 16),
+                                                   ("C4", 64, 4, 1 << 13)])
 def test_image_and_first_hit_small(rt, gpu, name, width, spp, n_rays):
-    scene, params, camera, sampler = rt.configs.build(name, image_width=width, samples_per_pixel=spp)
+    extra = {"mesh_grid": 1} if name == "C4" else {}
+    scene, params, camera, sampler = rt.configs.build(name, image_width=width, samples_per_pixel=spp, **extra)
     flat = scene.flatten()
     gpu.upload_scene(flat)
     gpu.upload_sampler(sampler)
