@@ -38,6 +38,7 @@ const rtg_graph *rth_scene_graph(rth_scene *s);
 int rth_add_solid_texture(rth_scene *s, float r, float g, float b);               /* solid_color_texture.rs:9-13 */
 int rth_add_checker_texture(rth_scene *s, int odd_tex, int even_tex, float repeat); /* checker_texture.rs:23-33 */
 int rth_add_noise_texture(rth_scene *s, float scale, uint32_t seed);              /* noise_texture.rs:13-18 + perlin.rs:65-82 */
+int rth_add_noise_texture_table(rth_scene *s, float scale, const rtg_perlin *table); /* same, caller-made PerlinNoise tables */
 int rth_add_image_texture(rth_scene *s, int width, int height, const uint8_t *rgba); /* image_texture.rs:40-47; 0x0 = blank() */
 int rth_add_lambertian(rth_scene *s, int albedo_tex);                             /* lambertian.rs:27-29 */
 int rth_add_metal(rth_scene *s, float r, float g, float b, float fuzz);           /* metal.rs:12-17 */

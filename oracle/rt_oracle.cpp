@@ -1253,6 +1253,11 @@ float orc_math(int32_t fn, float a, float b, int32_t use_libm) {
     return r;
 }
 
+float orc_perlin(const rtg_perlin *table, const float p[3], int32_t depth) {
+    PerlinNoise n{table};
+    return depth > 0 ? n.turbulence(V(p[0], p[1], p[2]), depth) : n.noise(V(p[0], p[1], p[2]));
+}
+
 float orc_lights_pdf_value(const orc_scene *s, const float o[3], const float v[3]) {
     GlobalOptions go(s);
     return s->lights->pdf_value(V(o[0], o[1], o[2]), V(v[0], v[1], v[2]));

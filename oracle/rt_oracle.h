@@ -64,6 +64,8 @@ void  orc_onb(const float n[3], float out_uvw9[9]);
 float orc_schlick(float cosine, float ior);
 void  orc_refract(const float uv[3], const float n[3], float etai_over_etat, float out[3]);
 float orc_math(int32_t fn /*0 sin 1 cos 2 acos 3 atan2 4 ln*/, float a, float b, int32_t use_libm);
+/* PerlinNoise::noise (turbulence_depth = 0) or ::turbulence(p, depth) on a caller-supplied table */
+float orc_perlin(const rtg_perlin *table, const float p[3], int32_t turbulence_depth);
 /* lights.pdf_value(o, v) and the scattering decision of one material for a given hit (KATs) */
 float orc_lights_pdf_value(const orc_scene *s, const float o[3], const float v[3]);
 

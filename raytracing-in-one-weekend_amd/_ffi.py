@@ -152,7 +152,7 @@ class rth_user_config(C.Structure):
 
 HOST_SYMBOLS = [
     "rth_last_error", "rth_scene_new", "rth_scene_free", "rth_scene_graph", "rth_add_solid_texture",
-    "rth_add_checker_texture", "rth_add_noise_texture", "rth_add_image_texture", "rth_add_lambertian", "rth_add_metal",
+    "rth_add_checker_texture", "rth_add_noise_texture", "rth_add_noise_texture_table", "rth_add_image_texture", "rth_add_lambertian", "rth_add_metal",
     "rth_add_dielectric", "rth_add_diffuse_light", "rth_add_isotropic", "rth_add_sphere", "rth_add_moving_sphere",
     "rth_add_rect", "rth_add_block", "rth_add_flip_face", "rth_add_translate", "rth_add_rotate_y", "rth_add_bvh",
     "rth_add_list", "rth_add_constant_medium", "rth_add_triangle_mesh", "rth_set_roots", "rth_geometry_import_glb",
@@ -189,6 +189,7 @@ def host_lib():
     L.rth_add_solid_texture.argtypes = [vp, f, f, f]
     L.rth_add_checker_texture.argtypes = [vp, i32, i32, f]
     L.rth_add_noise_texture.argtypes = [vp, f, u32]
+    L.rth_add_noise_texture_table.argtypes = [vp, f, C.c_void_p]
     L.rth_add_image_texture.argtypes = [vp, i32, i32, c_u8_p]
     L.rth_add_lambertian.argtypes = [vp, i32]
     L.rth_add_metal.argtypes = [vp, f, f, f, f]

@@ -258,6 +258,22 @@ int rth_add_noise_texture(rth_scene *s, float scale, uint32_t seed) {
     return push_texture(s, t);
 }
 
+int rth_add_noise_texture_table(rth_scene *s, float scale, const rtg_perlin *table) {
+    if (!table) { set_error("noise texture: null table"); return RT_E_INVALID; }
+    for (int i = 0; i < 256; ++i)
+        if ((uint32_t)table->perm_x[i] > 255u || (uint32_t)table->perm_y[i] > 255u || (uint32_t)table->perm_z[i] > 255u) {
+            set_error("noise texture: permutation entry outside 0..255");
+            return RT_E_INVALID;
+        }
+    s->perlins.push_back(*table);
+    rtg_texture t{};
+    t.type = RTG_TEX_NOISE;
+    t.scale = scale;
+    t.perlin = (int)s->perlins.size() - 1;
+    t.odd = t.even = t.image = -1;
+    return push_texture(s, t);
+}
+
 int rth_add_image_texture(rth_scene *s, int width, int height, const uint8_t *rgba) {
     rtg_texture t{};
     t.type = RTG_TEX_IMAGE;

@@ -216,6 +216,12 @@ class Scene:
     def checker(self, odd, even, repeat): return _check(_ffi.host_lib().rth_add_checker_texture(self._h, odd, even, repeat))
     def noise(self, scale, seed=0x5EED): return _check(_ffi.host_lib().rth_add_noise_texture(self._h, scale, seed))
 
+    def noise_table(self, scale, ranvec, perm_x, perm_y, perm_z):
+        tab = np.zeros(256 * 3 + 3 * 256, np.uint32)
+        tab[:768] = np.ascontiguousarray(ranvec, np.float32).reshape(768).view(np.uint32)
+        tab[768:1024], tab[1024:1280], tab[1280:] = perm_x, perm_y, perm_z
+        return _check(_ffi.host_lib().rth_add_noise_texture_table(self._h, scale, tab.ctypes.data))
+
     def image(self, rgba):
         if rgba is None:
             return _check(_ffi.host_lib().rth_add_image_texture(self._h, 0, 0, None))

@@ -1,0 +1,199 @@
+"""Oracle vs the hand-derived known answers of tests/golden/kat.json (bit-exact), plus the
+tie-break / wrapper quirks of the reference that have a closed-form expectation."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+rt = O.rt
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+INF = float("inf")
+
+
+def f32(bits):
+    return np.array(bits, dtype=np.uint32).view(np.float32)
+
+
+def ray(o, d, time=0.0):
+    return np.array([[o[0]], [o[1]], [o[2]], [d[0]], [d[1]], [d[2]], [time]], np.float32)
+
+
+def tmax(c):
+    return INF if c["t_max"] == "inf" else c["t_max"]
+
+
+def scene_with(build):
+    s = rt.host.Scene()
+    white = s.lambertian(s.solid(0.5, 0.5, 0.5))
+    objs = build(s, white)
+    light = s.xz_rect(0, 1, 0, 1, 100, s.diffuse_light(s.solid(0, 0, 0)))
+    s.set_roots(s.hittable_list(objs), s.hittable_list([light]))
+    return s
+
+
+def check_hit(scene, case, expect_uv=False):
+    o = O.OracleScene(scene)
+    pid, t, n, ff, uv = o.first_hit(ray(case["o"], case["d"]), case["t_min"], tmax(case))
+    want = case["hit"]
+    if want is None:
+        assert pid[0] == 0xFFFFFFFF
+        return
+    assert pid[0] == 0
+    assert t.view(np.uint32)[0] == want["t"]
+    assert list(n.view(np.uint32)[0]) == want["normal"]
+    assert ff[0] == want["front_face"]
+    if expect_uv:
+        assert list(uv.view(np.uint32)[0]) == want["uv"]
+
+
+@pytest.mark.parametrize("case", KAT["sphere"])
+def test_sphere(case):
+    check_hit(scene_with(lambda s, m: [s.sphere(case["center"], case["radius"], m)]), case)
+
+
+@pytest.mark.parametrize("case", KAT["rect"])
+def test_rect(case):
+    mk = {"xy": "xy_rect", "xz": "xz_rect", "yz": "yz_rect"}[case["kind"]]
+    check_hit(scene_with(lambda s, m: [getattr(s, mk)(case["a0"], case["a1"], case["b0"], case["b1"], case["k"], m)]), case, True)
+
+
+@pytest.mark.parametrize("case", KAT["aabb"])
+def test_aabb(case):
+    r = (C.c_float * 7)(*case["o"], *case["d"], 0.0)
+    got = O.lib().orc_aabb_hit((C.c_float * 3)(*case["min"]), (C.c_float * 3)(*case["max"]), r, case["t_min"], tmax(case))
+    assert got == case["hit"]
+
+
+def test_onb_schlick_refract():
+    for c in KAT["onb"]:
+        out = (C.c_float * 9)()
+        O.lib().orc_onb((C.c_float * 3)(*c["n"]), out)
+        assert list(np.array(list(out), np.float32).view(np.uint32)) == c["uvw"]
+    for c in KAT["schlick"]:
+        v = np.float32(O.lib().orc_schlick(c["cosine"], c["ior"]))
+        assert int(v.view(np.uint32)) == c["value"]
+    for c in KAT["refract"]:
+        out = (C.c_float * 3)()
+        O.lib().orc_refract((C.c_float * 3)(*c["uv"]), (C.c_float * 3)(*c["n"]), c["eta"], out)
+        got = np.array(list(out), np.float32).view(np.uint32)
+        want = np.array(c["value"], np.uint32)
+        nan = np.isnan(want.view(np.float32))
+        assert np.array_equal(got[~nan], want[~nan]) and np.isnan(got.view(np.float32)[nan]).all()
+
+
+def perlin_table():
+    p = KAT["perlin"]
+    tab = np.zeros(1536, np.uint32)
+    tab[:768] = np.array(p["ranvec"], np.uint32).reshape(768)
+    tab[768:1024], tab[1024:1280], tab[1280:] = p["perm_x"], p["perm_y"], p["perm_z"]
+    return tab
+
+
+def test_perlin_double_smoothing():
+    tab = perlin_table()
+    for c in KAT["perlin"]["noise"]:
+        v = np.float32(O.lib().orc_perlin(tab.ctypes.data, (C.c_float * 3)(*c["p"]), 0))
+        assert int(v.view(np.uint32)) == c["value"], c
+    for c in KAT["perlin"]["turbulence"]:
+        v = np.float32(O.lib().orc_perlin(tab.ctypes.data, (C.c_float * 3)(*c["p"]), 7))
+        assert int(v.view(np.uint32)) == c["value"], c
+
+
+def test_image_texel_addressing_and_blank():
+    img = np.zeros((2, 4, 4), np.uint8)
+    for j in range(2):
+        for i in range(4):
+            img[j, i] = (10 * i + j, 100 + i, 200 + j, 255)
+    s = rt.host.Scene()
+    tex = s.image(img)
+    blank = s.image(None)
+    m = s.lambertian(tex)
+    s.set_roots(s.hittable_list([s.sphere((0, 0, 0), 1, m)]), s.hittable_list([s.sphere((0, 5, 0), 1, m)]))
+    o = O.OracleScene(s)
+    for c in KAT["image"]:
+        i, j = c["ij"]
+        got = o.texture_value(tex, c["u"], c["v"], (0, 0, 0))
+        want = np.array([np.float32(1 / 255) * np.float32(x) for x in img[j, i, :3]], np.float32)
+        assert np.array_equal(got, want), c
+    assert list(o.texture_value(blank, 0.3, 0.3, (0, 0, 0))) == [0.0, 1.0, 1.0]   # image_texture.rs:57-59
+
+
+def test_list_tie_later_object_wins():
+    """hittable_list.rs:43-49: the comparator never returns Equal, so on equal t the LATER object is kept."""
+    s = scene_with(lambda s, m: [s.xy_rect(0, 1, 0, 1, 0, m), s.xy_rect(0, 1, 0, 1, 0, m), s.xy_rect(0, 1, 0, 1, 2, m)])
+    pid, t, *_ = O.OracleScene(s).first_hit(ray((0.5, 0.5, -1), (0, 0, 1)))
+    assert pid[0] == 1 and t[0] == 1.0
+
+
+def test_bvh_tie_right_child_wins():
+    """bvh.rs:83: `if a.t < b.t {a} else {b}` -> right."""
+    s = scene_with(lambda s, m: [s.bvh([s.xy_rect(0, 1, 0, 1, 0, m), s.xy_rect(0, 1, 0, 1, 0, m)])])
+    got = set()
+    for seed in range(8):   # either build order: the winner is whichever leaf ends up on the right
+        pid, *_ = O.OracleScene(s, bvh_seed=seed).first_hit(ray((0.5, 0.5, -1), (0, 0, 1)))
+        got.add(int(pid[0]))
+    assert got <= {0, 1} and len(got) >= 1
+
+
+def test_flip_face_and_translate_front_face_quirk():
+    """flip_face.rs flips only the flag; Translate re-runs HitRecord::new on the already
+    face-forwarded normal (transform.rs:36-44), which makes front_face true whatever it was."""
+    def build(s, m):
+        r = s.xz_rect(0, 1, 0, 1, 1, m)          # seen from below: outward n = +y, d = +y -> back face
+        return [s.flip_face(r)]
+    pid, t, n, ff, _ = O.OracleScene(scene_with(build)).first_hit(ray((0.5, 0, 0.5), (0, 1, 0)))
+    assert ff[0] == 1 and list(n[0]) == [0, -1, 0]       # flag flipped, normal untouched
+    def build2(s, m):
+        return [s.translate(s.flip_face(s.xz_rect(0, 1, 0, 1, 1, m)), (10, 0, 0))]
+    pid, t, n, ff, _ = O.OracleScene(scene_with(build2)).first_hit(ray((10.5, 0, 0.5), (0, 1, 0)))
+    assert ff[0] == 1 and list(n[0]) == [0, -1, 0]       # Translate recomputed it: true, flip lost
+    def build3(s, m):
+        return [s.flip_face(s.translate(s.xz_rect(0, 1, 0, 1, 1, m), (10, 0, 0)))]
+    pid, t, n, ff, _ = O.OracleScene(scene_with(build3)).first_hit(ray((10.5, 0, 0.5), (0, 1, 0)))
+    assert ff[0] == 0                                     # true from Translate, then flipped
+
+
+def test_rotate_y_block_hit_point():
+    """transform.rs:116-144: 90 degrees about Y maps the block [0,1]^3 to x in [0,1], z in [-1,0]."""
+    def build(s, m):
+        return [s.rotate_y(s.block((0, 0, 0), (1, 1, 1), m), 90.0)]
+    pid, t, n, ff, _ = O.OracleScene(scene_with(build)).first_hit(ray((0.5, 0.5, -3), (0, 0, 1)))
+    assert pid[0] != 0xFFFFFFFF and abs(t[0] - 2.0) < 1e-5 and ff[0] == 1
+    np.testing.assert_allclose(n[0], [0, 0, -1], atol=1e-6)
+
+
+def test_portable_math_close_to_libm():
+    """include/rt_portable_math.h vs glibc on the ranges the path uses: within a few ulp."""
+    rng = np.random.default_rng(1)
+    L = O.lib()
+    worst = 0.0
+    for fn, lo, hi in ((0, -700, 700), (1, -700, 700), (2, -1, 1), (4, 1e-7, 1.0)):
+        for x in rng.uniform(lo, hi, 4000).astype(np.float32):
+            a, b = np.float32(L.orc_math(fn, float(x), 0.0, 0)), np.float32(L.orc_math(fn, float(x), 0.0, 1))
+            ulp = np.spacing(np.float32(max(abs(b), 1e-3 if fn < 2 else abs(b))))
+            worst = max(worst, abs(float(a) - float(b)) / float(ulp))
+    for y, x in rng.uniform(-5, 5, (4000, 2)).astype(np.float32):
+        a, b = np.float32(L.orc_math(3, float(y), float(x), 0)), np.float32(L.orc_math(3, float(y), float(x), 1))
+        worst = max(worst, abs(float(a) - float(b)) / float(np.spacing(np.float32(max(abs(b), 1e-3)))))
+    assert worst <= 8.0, worst
+    assert L.orc_math(4, 0.0, 0.0, 0) == -INF        # ln(0) = -inf (constant_medium.rs:78 relies on it)
+
+
+def test_mesh_first_hit_vs_nearest_modes():
+    """the reference returns the FIRST triangle in index order that hits, not the nearest."""
+    verts = np.array([[0, 0, 5, 0, 0, -1, 0, 0], [1, 0, 5, 0, 0, -1, 1, 0], [0, 1, 5, 0, 0, -1, 0, 1],      # far triangle first
+                      [0, 0, 2, 0, 0, -1, 0, 0], [1, 0, 2, 0, 0, -1, 1, 0], [0, 1, 2, 0, 0, -1, 0, 1]], np.float32)
+    idx = np.array([0, 1, 2, 3, 4, 5], np.uint32)
+    nodes = np.array([[0, 6]], np.uint32)
+    def build(s, m):
+        return [s.triangle_mesh(verts, idx, nodes, np.eye(4), m)]
+    sc = scene_with(build)
+    r = ray((0.2, 0.2, 0), (0, 0, 1))
+    pid, t, *_ = O.OracleScene(sc, mesh_nearest=False).first_hit(r)
+    assert pid[0] == 0 and t[0] == 5.0
+    pid, t, *_ = O.OracleScene(sc, mesh_nearest=True).first_hit(r)
+    assert pid[0] == 1 and t[0] == 2.0
