@@ -1,0 +1,240 @@
+"""Host logic (librtiow_host.so): config, params, camera, sampler, scene builders, GLB import, flatten/BVH."""
+import ctypes as C
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+
+
+def test_config_ron_matches_the_shipped_file(rt):
+    cfg = rt.host.RaytracerConfig.load()
+    assert cfg.active_scene == "Blocks"                          # raytracer.config.ron:2
+    p = cfg.scene_params("RandomWorld")                          # :25-44
+    assert (p.workers, p.image_width, p.samples_per_pixel, p.max_ray_depth) == (12, 800, 144, 50)
+    assert p.look_from == [13.0, 2.0, 3.0] and p.aperture == pytest.approx(0.1) and p.projection_name == "Perspective"
+    assert p.background == pytest.approx([0.5, 0.8, 0.99])
+    d = cfg.scene_params("CornellBox")                           # (CornellBox, None) -> default_params :3-21
+    assert d.look_from == [278.0, 278.0, -800.0] and d.samples_per_pixel == 256 and d.image_width == 800
+    assert d.image_height == int(np.float32(800) / np.float32(1.77777))   # main.rs:1180
+    g = cfg.scene_params("GeometricPrimitives")
+    assert g.projection_name == "SphericalPanoramic" and g.psi_max == 360.0
+    assert cfg.scene_params().worker_block_pixels == 8           # active scene
+    with pytest.raises(rt.RtError):
+        cfg.scene_params("TexturedSpheres")                      # not in defined_scenes -> "Specified scene not found"
+
+
+def test_config_parser_errors_and_syntax(rt):
+    text = open(rt.host.DEFAULT_CONFIG).read()
+    cfg = rt.host.RaytracerConfig.parse("// c\n" + text.replace("active_scene: Blocks", "active_scene: /* x */ MeshTest"))
+    assert cfg.active_scene == "MeshTest"
+    for bad in ("(", "(active_scene: Blocks)", text.replace("workers: 8,", "", 1), text.replace("Perspective", "Cubist")):
+        with pytest.raises(rt.RtError):
+            rt.host.RaytracerConfig.parse(bad)
+    with pytest.raises(rt.RtError):
+        rt.host.RaytracerConfig.load("/nonexistent/raytracer.config.ron")
+
+
+def test_work_blocks_follow_main_rs(rt):
+    b = rt.host.work_blocks(1200, 675, 8)                        # 151 x 85 = 12 835 blocks
+    assert b.shape == (151 * 85, 4)
+    area = ((b[:, 1] - b[:, 0]) * (b[:, 3] - b[:, 2])).sum()
+    assert area == 1200 * 675
+    assert (b[:, 1] == b[:, 0]).sum() == 85 + 0                  # 1200/8 is exact: the extra column is empty
+    assert b[:, 1].max() == 1200 and b[:, 3].max() == 675
+
+
+def test_camera_new_known_answer(rt):
+    cam = rt.host.Camera.new((0, 0, 0), (0, 0, -1), (0, 1, 0), 90.0, 2.0, 2.0, 1.0)
+    np.testing.assert_allclose(list(cam.w), [0, 0, 1], atol=0)
+    np.testing.assert_allclose(list(cam.u), [1, 0, 0], atol=0)
+    np.testing.assert_allclose(list(cam.v), [0, 1, 0], atol=0)
+    np.testing.assert_allclose(list(cam.lower_left_corner), [-2, -1, -1], rtol=1e-6)   # half_h = tan(45deg) = 1, half_w = 2
+    np.testing.assert_allclose(list(cam.horizontal), [4, 0, 0], rtol=1e-6)
+    np.testing.assert_allclose(list(cam.vertical), [0, 2, 0], rtol=1e-6)
+    assert cam.lens_radius == 1.0 and (cam.time0, cam.time1) == (0.0, 1.0)
+
+
+@pytest.mark.parametrize("spp", [9, 16, 10, 1000, 1])
+def test_sampler_table_properties(rt, spp):
+    s = rt.host.MultiJitteredSampler(spp, seed=3)
+    sq, disk, idx = s.arrays()
+    assert s.desc.sets == 83 and sq.shape == (83 * spp, 2)
+    for p in range(83):
+        blk = sq[p * spp:(p + 1) * spp]
+        assert (blk >= 0).all() and (blk < 1.0 + 1e-6).all()
+        # n-rooks: exactly one point per sub-cell column and per row, also after the coordinate shuffles
+        for c in range(2):
+            x = np.sort(blk[:, c].astype(np.float64)) * spp      # k-th smallest lies in sub-cell k (f32 rounding slack)
+            k = np.arange(spp)
+            assert (x >= k - 1e-3).all() and (x <= k + 1 + 1e-3).all(), (p, c)
+        assert np.array_equal(np.sort(idx[p * spp:(p + 1) * spp]), np.arange(spp))
+    assert (np.hypot(disk[:, 0], disk[:, 1]) <= 1.0 + 1e-5).all()
+    s2 = rt.host.MultiJitteredSampler(spp, seed=3)
+    assert all(np.array_equal(a, b) for a, b in zip(s.arrays(), s2.arrays()))
+    if spp > 1:
+        s3 = rt.host.MultiJitteredSampler(spp, seed=4)
+        assert not np.array_equal(s.arrays()[0], s3.arrays()[0])
+
+
+def test_multijittered_square_spp_keeps_the_reference_grid(rt):
+    """sampling.rs:242-245 before the shuffles: x in sub-cell i*n+j, y in sub-cell j*n+i.  After the
+    x/y shuffles only the multiset of sub-cells survives, which the n-rooks test covers; here: spp=1 and 4."""
+    s = rt.host.MultiJitteredSampler(4, sets=2, seed=1)
+    sq, _, _ = s.arrays()
+    assert sq.shape == (8, 2)
+
+
+def test_mat4_reference_known_answer(rt):
+    k = KAT["mat4_mul"]                                           # math/src/mat4.rs:641-655
+    out = (C.c_float * 16)()
+    rt._ffi.host_lib().rth_mat4_mul((C.c_float * 16)(*k["a"]), (C.c_float * 16)(*k["b"]), out)
+    assert list(out) == k["result"]
+    m = np.array([[2, 0, 0, 1], [0, 4, 0, 2], [0, 0, 8, 3], [0, 0, 0, 1]], np.float32)
+    rt._ffi.host_lib().rth_mat4_invert((C.c_float * 16)(*m.reshape(16)), out)
+    np.testing.assert_allclose(np.array(list(out)).reshape(4, 4) @ m, np.eye(4), atol=1e-6)
+    assert rt._ffi.host_lib().rth_mat4_invert((C.c_float * 16)(*([0.0] * 16)), out) < 0
+
+
+def graph_counts(scene):
+    g = scene.graph().contents
+    types = [g.nodes[i].type for i in range(g.n_nodes)]
+    return g, types
+
+
+def test_scene_builders_object_counts(rt):
+    s = rt.host.Scene.build("CornellBox")
+    g, types = graph_counts(s)
+    world = g.nodes[g.world_root]
+    assert world.child_count == 8                                 # main.rs:387-502
+    assert g.nodes[g.lights_root].child_count == 2
+    f = s.flatten()
+    assert f.desc.n_prims == 13 and f.desc.always_count == 13 and f.desc.n_lights == 2 and f.desc.n_xforms == 1
+
+    s = rt.host.Scene.build("RandomWorld", seed=1)
+    g, types = graph_counts(s)
+    n_world = g.nodes[g.world_root].child_count
+    assert 400 < n_world <= 488                                   # 1 + 22*22 (minus rejected) + 3
+    moving = types.count(1)
+    assert 0.7 < moving / (n_world - 4) < 0.9                     # ~80 % moving Lambertian, main.rs:131
+    f = s.flatten()
+    assert f.desc.n_prims == n_world and f.desc.n_moving_slots == moving and f.desc.n_lights == 1
+    s2 = rt.host.Scene.build("RandomWorld", seed=1)
+    assert np.array_equal(s2.flatten().slots(), f.slots())        # seeded: reproducible
+    assert not np.array_equal(rt.host.Scene.build("RandomWorld", seed=2).flatten().slots()[:50], f.slots()[:50])
+
+    assets = rt.host.Assets(need=("earthmap",))
+    s = rt.host.Scene.build("Chapter2Final", assets=assets)
+    g, _ = graph_counts(s)
+    assert g.nodes[g.world_root].child_count == 11                # main.rs:715-814
+    f = s.flatten()
+    assert f.desc.n_prims == 400 * 6 + 1 + 5 + 2 + 1000 + 1       # SURVEY: 3 409 leaf prims (2 media among them)
+    assert f.desc.n_slots == f.desc.n_prims - 2 and f.desc.n_media == 2 and f.desc.n_perlin == 1
+    assert f.desc.n_texel_bytes == 1024 * 512 * 4
+    with pytest.raises(rt.RtError):
+        rt.host.Scene.build("Blocks")
+
+
+def check_bvh(flat):
+    nodes, slots, d = flat.nodes(), flat.slots(), flat.desc
+    seen = np.zeros(d.n_slots, np.int32)
+    max_depth = [0]
+
+    def leaf_slots(ref):
+        code = ~ref & 0xFFFFFFFF
+        return range(code >> 3, (code >> 3) + (code & 7) + 1)
+
+    def walk(ref, depth):
+        max_depth[0] = max(max_depth[0], depth)
+        if ref < 0:
+            for s in leaf_slots(ref):
+                seen[s] += 1
+            return
+        n = nodes[ref]
+        refs = n[12:14].view(np.int32)
+        for c in range(2):
+            walk(int(refs[c]), depth + 1)
+    walk(d.bvh_root_ref, 0)
+    assert (seen == 1).all(), "every slot must sit in exactly one leaf"
+    assert max_depth[0] + 1 <= d.bvh_stack_depth
+    ids = slots[:, 6].view(np.int32)
+    assert len(set(ids.tolist())) == d.n_slots
+
+
+def test_flatten_bvh_invariants(rt):
+    f = rt.host.Scene.build("RandomWorld").flatten()
+    check_bvh(f)
+    f = rt.host.Scene.build("Chapter2Final", assets=rt.host.Assets(need=("earthmap",))).flatten()
+    check_bvh(f)
+    slots = f.slots()
+    w4 = slots[:, 4].view(np.int32)
+    assert ((w4 >> 8) > 0).sum() == 1000                          # the 1000 spheres carry the Translate(RotateY) record
+    assert ((w4 & 16) != 0).sum() == 1                            # one FlipFace'd light
+
+
+def test_unsupported_nesting_is_reported(rt):
+    s = rt.host.Scene()
+    m = s.lambertian(s.solid(1, 1, 1))
+    inner = s.rotate_y(s.translate(s.sphere((0, 0, 0), 1, m), (1, 0, 0)), 10.0)
+    s.set_roots(s.hittable_list([inner]), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
+    with pytest.raises(rt.RtError) as e:
+        s.flatten()
+    assert e.value.status == -5
+
+
+def read_glb_positions(path):
+    d = open(path, "rb").read()
+    jlen = struct.unpack("<I", d[12:16])[0]
+    j = json.loads(d[20:20 + jlen])
+    off = 20 + ((jlen + 3) & ~3) + 8
+    out = []
+    for mesh in j["meshes"]:
+        acc = j["accessors"][mesh["primitives"][0]["attributes"]["POSITION"]]
+        bv = j["bufferViews"][acc["bufferView"]]
+        out.append(np.frombuffer(d, np.float32, acc["count"] * 3, off + bv.get("byteOffset", 0)).reshape(-1, 3))
+    return out
+
+
+def test_glb_import_counts_and_quaternion_quirk(rt):
+    path = os.path.join(rt.host.DATA_DIR, "models/teapot/teapot.glb")
+    geo = rt.host.Geometry(path)
+    verts, idx, nodes = geo.view()
+    assert verts.shape[0] == 10070 + 3763 and idx.shape[0] == 52392 + 15546
+    assert nodes.tolist() == [[0, 52392], [52392, 15546]]
+    assert idx[52392:].min() == 10070                                                  # indices rebased to the global vertex array
+    raw = np.concatenate(read_glb_positions(path))
+    # identity TRS read as quaternion (w,x,y,z) = (0,0,0,1) -> diag(-1,-1,1)
+    assert np.array_equal(verts[:, 0], -raw[:, 0]) and np.array_equal(verts[:, 1], -raw[:, 1]) and np.array_equal(verts[:, 2], raw[:, 2])
+    np.testing.assert_allclose(np.linalg.norm(verts[:, 3:6], axis=1), 1.0, atol=1e-5)
+    with pytest.raises(rt.RtError):
+        rt.host.Geometry("/nonexistent.glb")
+
+
+def test_mesh_scene_teapot_stands_on_the_floor(rt):
+    assets = rt.host.Assets(need=("uvgrid01", "uvgrid09", "teapot"))
+    s = rt.host.Scene.build("MeshTest", assets=assets)
+    g = s.graph().contents
+    assert g.n_meshes == 1
+    m = g.meshes[0]
+    v = np.ctypeslib.as_array(C.cast(m.vertices, rt._ffi.c_float_p), (m.n_vertices, 8))
+    raw = np.concatenate(read_glb_positions(os.path.join(rt.host.DATA_DIR, "models/teapot/teapot.glb")))
+    np.testing.assert_allclose(v[:, :3], raw * np.array([-1, 1, -1], np.float32), atol=2e-6)   # net (x,y,z) -> (-x,y,-z)
+    assert v[:, 1].min() > -1e-5 and 12.9 < v[:, 1].max() < 13.0
+    f = s.flatten()
+    assert f.desc.n_prims == 22646 + 2
+    check_bvh(f)
+
+
+def test_sample_range_sharding(rt):
+    sr = rt.sharding.sample_range
+    for spp, world in ((1000, 8), (10, 3), (7, 8), (16384, 8)):
+        ranges = [sr(r, world, spp) for r in range(world)]
+        pos = 0
+        for b, c in ranges:
+            assert b == pos and c >= 0
+            pos += c
+        assert pos == spp and max(c for _, c in ranges) - min(c for _, c in ranges) <= 1
