@@ -408,22 +408,23 @@ template <bool STATS>
 RT_DEV void closest_hit_exhaustive(const DScene &sc, const Ray &r, float t_min, float t_max, const float *med_t, const bool *med_ok,
                                    Hit &best, Counters &cnt) {
     int32_t last_nan_id = -1, last_nan_slot = 0;
+    float last_nan_t = 0.0f;
     int32_t last_id = -1;
     for (uint32_t s = 0; s < sc.n_slots; ++s) {
         float t; int32_t id;
         if (!slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt)) continue;
         if (id > last_id) last_id = id;
-        if (t != t && id > last_nan_id) { last_nan_id = id; last_nan_slot = (int32_t)s; }
+        if (t != t && id > last_nan_id) { last_nan_id = id; last_nan_slot = (int32_t)s; last_nan_t = t; }
     }
     for (uint32_t m = 0; m < sc.n_media; ++m) {
         if (!med_ok[m]) continue;
         int32_t id = f2i(sc.media[2 * m + 1].z);
         if (id > last_id) last_id = id;
-        if (med_t[m] != med_t[m] && id > last_nan_id) { last_nan_id = id; last_nan_slot = -(int32_t)(m + 1); }
+        if (med_t[m] != med_t[m] && id > last_nan_id) { last_nan_id = id; last_nan_slot = -(int32_t)(m + 1); last_nan_t = med_t[m]; }
     }
     best.t = INFINITY; best.id = -1; best.slot = 0;
     if (last_id < 0) return;
-    if (last_nan_id == last_id) { best.t = __int_as_float(0x7fc00000); best.id = last_nan_id; best.slot = last_nan_slot; return; }
+    if (last_nan_id == last_id) { best.t = last_nan_t; best.id = last_nan_id; best.slot = last_nan_slot; return; }
     bool any = false;
     for (uint32_t s = 0; s < sc.n_slots; ++s) {
         float t; int32_t id;
