@@ -153,8 +153,11 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_ffi as O   # cpu_baseline leg only: the oracle is the checker/baseline, never the product
             cores = min(16, os.cpu_count() or 1)
-            sample_spp = max(1, min(base_spp, int(32 * (600 * 600) / (W * H)) or 1))
             oracle = O.OracleScene(scene)
+            c0 = time.perf_counter()
+            _, cal_rays = oracle.render(params, camera, sampler, spp_begin=0, spp_count=1, threads=cores)   # calibration, untimed
+            cal = time.perf_counter() - c0
+            sample_spp = max(1, min(base_spp, int(15.0 / max(cal, 1e-3))))                                   # about 15 s of CPU work
             c0 = time.perf_counter()
             _, c_rays = oracle.render(params, camera, sampler, spp_begin=0, spp_count=sample_spp, threads=cores)
             c_dt = time.perf_counter() - c0
