@@ -103,6 +103,9 @@ typedef struct rt_scene_desc {
     const uint32_t *moving_slots;   uint32_t n_moving_slots; /* slot indices of every MovingSphere: tested
                                        directly when ray.time is outside the shutter interval the BVH boxes cover
                                        (isotropic.rs:32 puts hit.t into ray.time) */
+    const uint32_t *rect_slots;     uint32_t n_rect_slots;   /* slot indices of every rectangle: the only leaves whose
+                                       hit test can ACCEPT a NaN distance for a finite ray (0/0 when the ray lies in the
+                                       plane, rectangles.rs:23-34); scanned when a direction component is exactly 0 */
     uint32_t       n_prims;         /* number of primitive ids in the scene */
 } rt_scene_desc;
 

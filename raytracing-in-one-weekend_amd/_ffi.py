@@ -44,6 +44,7 @@ class rt_scene_desc(C.Structure):
         ("perlin", c_u32_p), ("n_perlin", C.c_uint32),
         ("texels", c_u8_p), ("n_texel_bytes", C.c_uint64),
         ("moving_slots", c_u32_p), ("n_moving_slots", C.c_uint32),
+        ("rect_slots", c_u32_p), ("n_rect_slots", C.c_uint32),
         ("n_prims", C.c_uint32),
     ]
 

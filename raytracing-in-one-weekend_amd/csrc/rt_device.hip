@@ -156,6 +156,8 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     if (tris && !s->tri_attrs) return fail(ctx, RT_E_INVALID, "triangles without tri_attrs");
     for (uint32_t i = 0; i < s->n_moving_slots; ++i)
         if (s->moving_slots[i] >= s->n_slots) return fail(ctx, RT_E_INVALID, "moving slot out of range");
+    for (uint32_t i = 0; i < s->n_rect_slots; ++i)
+        if (s->rect_slots[i] >= s->n_slots) return fail(ctx, RT_E_INVALID, "rect slot out of range");
     for (uint32_t i = 0; i < s->n_materials; ++i) {
         int32_t type, tex;
         memcpy(&type, &s->materials[i * RT_REC_FLOATS], 4);
@@ -199,11 +201,12 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     UP(perlin, s->perlin, (size_t)s->n_perlin * RT_PERLIN_WORDS * 4);
     UP(texels, s->texels, (size_t)s->n_texel_bytes);
     UP(moving, s->moving_slots, (size_t)s->n_moving_slots * 4);
+    UP(rects, s->rect_slots, (size_t)s->n_rect_slots * 4);
 #undef UP
     d.root_ref = s->bvh_root_ref;
     d.n_slots = s->n_slots;
     d.always_begin = s->always_begin; d.always_count = s->always_count;
-    d.n_media = s->n_media; d.n_lights = s->n_lights; d.n_moving = s->n_moving_slots;
+    d.n_media = s->n_media; d.n_lights = s->n_lights; d.n_moving = s->n_moving_slots; d.n_rects = s->n_rect_slots;
     ctx->stack_depth = s->bvh_stack_depth;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_scene = true;

@@ -59,7 +59,7 @@ struct rth_flat {
     std::vector<float> xforms, media, lights, materials, textures;
     std::vector<uint32_t> perlin;
     std::vector<uint8_t> texels;
-    std::vector<uint32_t> moving;
+    std::vector<uint32_t> moving, rects;
     int32_t root_ref = RT_BVH_EMPTY;
     uint32_t stack_depth = 1, always_begin = 0, always_count = 0, n_prims = 0;
     bool has_tris = false;
@@ -142,6 +142,7 @@ struct Flattener {
         if (gtype == RTG_XY_RECT) { type = RT_PRIM_XY_RECT; b = Box{{f[0], f[2], k}, {f[1], f[3], k}}; }
         else if (gtype == RTG_XZ_RECT) { type = RT_PRIM_XZ_RECT; b = Box{{f[0], k, f[2]}, {f[1], k, f[3]}}; }
         else { type = RT_PRIM_YZ_RECT; b = Box{{k, f[0], f[2]}, {k, f[1], f[3]}}; }
+        out->rects.push_back((uint32_t)prims.size());
         emit(type, w, material, q0, k, nullptr, b, nullptr);
     }
 
@@ -498,6 +499,7 @@ int rth_flatten(const rtg_graph *g, rth_flat **out_flat) {
         flat->always_begin = flat->always_count = 0;
     }
     for (auto &m : flat->moving) m = new_index[m];
+    for (auto &m : flat->rects) m = new_index[m];
     if (!flat->has_tris) flat->attrs.clear();
     *out_flat = flat.release();
     return RT_OK;
@@ -521,6 +523,7 @@ void rth_flat_desc(const rth_flat *f, rt_scene_desc *d) {
     d->perlin = f->perlin.data();              d->n_perlin = (uint32_t)(f->perlin.size() / RT_PERLIN_WORDS);
     d->texels = f->texels.data();              d->n_texel_bytes = f->texels.size();
     d->moving_slots = f->moving.data();        d->n_moving_slots = (uint32_t)f->moving.size();
+    d->rect_slots = f->rects.data();           d->n_rect_slots = (uint32_t)f->rects.size();
     d->n_prims = f->n_prims;
 }
 

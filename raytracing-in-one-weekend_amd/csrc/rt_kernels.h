@@ -86,11 +86,12 @@ struct DScene {
     const uint32_t *perlin;
     const uint32_t *texels;
     const uint32_t *moving;
+    const uint32_t *rects;
     const float2 *samples;
     const float2 *disk;
     const uint32_t *shuffled;
     int32_t root_ref;
-    uint32_t n_slots, always_begin, always_count, n_media, n_lights, n_moving, sets, spp;
+    uint32_t n_slots, always_begin, always_count, n_media, n_lights, n_moving, n_rects, sets, spp;
 };
 
 struct Counters {  // only live in the STATS instantiation
@@ -324,7 +325,7 @@ RT_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv, float t_min, float t_max, float *t_
 }
 
 template <bool STATS>
-RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, Hit &best, uint2 *stack, uint32_t stride, Counters &cnt) {
+RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_id, Hit &best, uint2 *stack, uint32_t stride, Counters &cnt) {
     int32_t ref = sc.root_ref;
     if (ref == RT_BVH_EMPTY) return;
     V3 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
@@ -355,7 +356,7 @@ RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, Hit &best, uin
             for (uint32_t i = 0; i < count; ++i) {
                 float t;
                 int32_t id;
-                if (slot_hit<STATS>(sc, first + i, r, t_min, best.t, &t, &id, cnt)) consider(best, t, id, (int32_t)(first + i));
+                if (slot_hit<STATS>(sc, first + i, r, t_min, best.t, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)(first + i));
             }
         }
         // pop; entries whose box starts beyond the current best cannot contain a closer-or-equal hit
@@ -392,12 +393,13 @@ RT_DEV bool medium_hit(const DScene &sc, uint32_t m, const Ray &r, float t_min, 
 
 RT_DEV bool finite_f(float x) { return fabsf(x) < INFINITY; }
 
-// Rays the BVH cannot serve with reference semantics: a non-finite or zero direction component
-// (NaN hit distances are ACCEPTED by the reference's comparisons, sphere.rs:61-65,
-// rectangles.rs:25-32, and the list fold then keeps the last such object), or a non-finite origin.
-RT_DEV bool ray_is_regular(const Ray &r) {
+// Rays the BVH cannot serve with reference semantics: anything non-finite, or a null direction.
+// NaN hit distances are ACCEPTED by the reference's comparisons (sphere.rs:61-65,
+// rectangles.rs:25-32) and the list fold then keeps the last such object; those rays take the
+// literal fold over all slots.
+RT_DEV bool ray_is_finite(const Ray &r) {
     return finite_f(r.o.x) && finite_f(r.o.y) && finite_f(r.o.z) && finite_f(r.d.x) && finite_f(r.d.y) && finite_f(r.d.z) &&
-           r.d.x != 0.0f && r.d.y != 0.0f && r.d.z != 0.0f && finite_f(r.time);
+           finite_f(r.time) && !(r.d.x == 0.0f && r.d.y == 0.0f && r.d.z == 0.0f);
 }
 
 // The reference's fold, literally: candidates in list order, `best` replaced unless best.t < t.
@@ -453,10 +455,22 @@ RT_DEV bool closest_hit(const DScene &sc, const Ray &r, float t_min, float t_max
         med_ok[m] = false; med_t[m] = 0.0f;
         if (with_media && m < sc.n_media) med_ok[m] = medium_hit<STATS>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
     }
-    if (!ray_is_regular(r)) {
+    if (!ray_is_finite(r)) {
         closest_hit_exhaustive<STATS>(sc, r, t_min, t_max, med_t, med_ok, best, cnt);
         return best.id >= 0;
     }
+    // A finite ray gets a NaN distance from exactly one kind of leaf: a rectangle whose plane
+    // contains the ray (d[axis] == 0 and o[axis] == k -> 0/0).  The fold keeps only what comes after
+    // the last such candidate, so find it first (rect list only) and let everything else pass a
+    // "later than that" filter.  Costs nothing unless a direction component is exactly zero.
+    int32_t floor_id = -1, nan_slot = 0;
+    float nan_t = 0.0f;
+    if (r.d.x == 0.0f || r.d.y == 0.0f || r.d.z == 0.0f)
+        for (uint32_t i = 0; i < sc.n_rects; ++i) {
+            float t; int32_t id;
+            uint32_t s = sc.rects[i];
+            if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt) && t != t && id > floor_id) { floor_id = id; nan_slot = (int32_t)s; nan_t = t; }
+        }
     best.t = t_max; best.id = -1; best.slot = 0;
     bool any = false;
     // t == t_max is accepted by every leaf (e.g. `t > t_max` rejects, rectangles.rs:25), so the
@@ -464,19 +478,20 @@ RT_DEV bool closest_hit(const DScene &sc, const Ray &r, float t_min, float t_max
     for (uint32_t i = 0; i < sc.always_count; ++i) {
         float t; int32_t id;
         uint32_t s = sc.always_begin + i;
-        if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt)) consider(best, t, id, (int32_t)s);
+        if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)s);
     }
-    traverse<STATS>(sc, r, t_min, best, stack, stride, cnt);
+    traverse<STATS>(sc, r, t_min, floor_id, best, stack, stride, cnt);
     // MovingSphere boxes cover the shutter interval only; isotropic.rs:32 can hand a ray any "time"
     if (sc.n_moving && !(r.time >= 0.0f && r.time <= 1.0f))
         for (uint32_t i = 0; i < sc.n_moving; ++i) {
             float t; int32_t id;
             uint32_t s = sc.moving[i];
-            if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt)) consider(best, t, id, (int32_t)s);
+            if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)s);
         }
 #pragma unroll
     for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m)
-        if (med_ok[m]) consider(best, med_t[m], f2i(sc.media[2 * m + 1].z), -(int32_t)(m + 1));
+        if (med_ok[m] && f2i(sc.media[2 * m + 1].z) > floor_id) consider(best, med_t[m], f2i(sc.media[2 * m + 1].z), -(int32_t)(m + 1));
+    if (best.id < 0 && floor_id >= 0) { best.t = nan_t; best.id = floor_id; best.slot = nan_slot; }   // the NaN candidate was the last one
     any = best.id >= 0;
     return any;
 }

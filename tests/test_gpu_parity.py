@@ -95,3 +95,50 @@ def test_image_and_first_hit_small(rt, gpu, name, width, spp, n_rays):
     rays2 = bounce_rays(rays, g[1], g[2], hit)
     check_first_hit(gpu, oracle, rays2)
     compare_images(rt, gpu, oracle, params, camera, sampler)
+
+
+def test_degenerate_rays_follow_the_reference_fold(rt, gpu):
+    """Zero direction components, rays lying in a rectangle's plane (NaN distance, accepted by
+    rectangles.rs:25-32), NaN / zero directions: the GPU must return what the list fold returns."""
+    def build(order):
+        s = rt.host.Scene()
+        m = s.lambertian(s.solid(0.5, 0.5, 0.5))
+        objs = {"rect": lambda: s.xy_rect(0, 1, 0, 1, 0, m), "sphere": lambda: s.sphere((3, 0.5, 0), 0.5, m),
+                "far_rect": lambda: s.yz_rect(-5, 5, -5, 5, 9, m)}
+        world = [objs[k]() for k in order]
+        s.set_roots(s.hittable_list(world), s.hittable_list([s.xz_rect(0, 1, 0, 1, 100, s.diffuse_light(s.solid(0, 0, 0)))]))
+        return s
+    rays = np.array([
+        [0.5, 0.5, 0, 1, 0, 0, 0],          # in the plane z = 0 of `rect`: t = NaN there; sphere and far_rect are real hits
+        [0.5, 0.5, 0, 1, 0.01, 0, 0],       # one zero component, nothing degenerate
+        [-1, 0.5, 0, 1, 0, 0, 0],           # same line, starting outside the rectangle: still 0/0
+        [0.5, 0.5, 1, 1, 0, 0, 0],          # parallel above the plane: -inf / +inf, rejected
+        [0.5, 0.5, -1, 0, 0, 1, 0],         # straight at the rectangle: two zero components
+        [0.5, 0.5, -1, 0, 0, 0, 0],         # null direction
+        [0.5, 0.5, -1, np.nan, 0, 1, 0],    # NaN direction: every leaf "hits"
+        [np.inf, 0.5, -1, 0, 0, 1, 0],
+    ], np.float32).T.copy()
+    for order in (("rect", "sphere", "far_rect"), ("sphere", "far_rect", "rect"), ("far_rect", "rect", "sphere")):
+        scene = build(order)
+        gpu.upload_scene(scene.flatten())
+        g = gpu.trace_first_hit(rays)
+        c = O.OracleScene(scene).first_hit(rays)
+        assert np.array_equal(g[0], c[0]), (order, g[0], c[0])
+        assert np.array_equal(np.isnan(g[1]), np.isnan(c[1])), order
+        ok = ~np.isnan(c[1])
+        assert np.array_equal(g[1][ok], c[1][ok]) and np.array_equal(g[3], c[3])
+    # a BVH scene: zero out one direction component of ordinary rays
+    scene, params, camera, sampler = rt.configs.build("C3", image_width=64, samples_per_pixel=4)
+    gpu.upload_scene(scene.flatten())
+    r = primary_and_bounce_rays(rt, scene, params, camera, 6000)
+    r[3, :2000] = 0; r[4, 2000:4000] = 0; r[5, 4000:] = 0
+    r[1, :100] = 0.0          # origins ON the y = 0 plane of the ground boxes (d.y != 0 there: t = 0 < t_min)
+    # Not tested against the BVH oracle: rays lying exactly IN a face plane of leaves that sit inside a
+    # reference BvhNode (camera z = -600 is such a plane).  Their NaN candidates are folded in the
+    # BvhNode's leaf order, which follows the reference's RANDOM split axes (bvh.rs:17) — the reference
+    # itself does not reproduce that case from run to run.  Move those rays off the plane.
+    r[2, 4000:] = -612.3
+    g = gpu.trace_first_hit(r)
+    c = O.OracleScene(scene).first_hit(r)
+    assert np.array_equal(g[0], c[0]) and np.array_equal(g[1], c[1]) and np.array_equal(g[3], c[3])
+    assert (g[0] != 0xFFFFFFFF).mean() > 0.2
