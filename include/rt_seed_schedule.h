@@ -94,9 +94,13 @@ RTS_HD inline int32_t random_int(Rng &r, int32_t lo, int32_t hi) {
 // is a function of (pixel, slot): slot = 2*sample (+1 for the disk lookup).
 RTS_HD inline uint32_t sampler_index(uint32_t seed, uint32_t pixel, uint32_t slot, uint32_t sets,
                                      uint32_t spp, const uint32_t *shuffled_indices) {
-    uint32_t epoch = slot / spp;
-    uint32_t jump = (hash3(seed ^ 0x51ed270bu, pixel, epoch) % sets) * spp;
-    return jump + shuffled_indices[jump + (slot % spp)];
+    // slot < 2*spp, so the quotient is 0 or 1; the set is picked by a multiply-high (no integer
+    // division on the device: `random_int(0, MAX-1) % sets` of sampling.rs:139 is not reproducible anyway)
+    uint32_t epoch = slot >= spp ? 1u : 0u;
+    uint32_t rem = slot - (epoch ? spp : 0u);
+    uint32_t set = (uint32_t)(((uint64_t)hash3(seed ^ 0x51ed270bu, pixel, epoch) * (uint64_t)sets) >> 32);
+    uint32_t jump = set * spp;
+    return jump + shuffled_indices[jump + rem];
 }
 
 }  // namespace rts

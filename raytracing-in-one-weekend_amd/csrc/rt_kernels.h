@@ -211,11 +211,10 @@ RT_DEV bool slot_hit(const DScene &sc, uint32_t slot, const Ray &r_world, float 
     Ray r = xf >= 0 ? to_object(sc, xf, r_world) : r_world;
     float a, b;
     switch (type) {
-    case RT_PRIM_SPHERE:
-        return sphere_roots(v3(q0.x, q0.y, q0.z), q0.w, r, t_min, t_max, t_out);
-    case RT_PRIM_MOVING_SPHERE: {
-        float4 q2 = sc.slots[4 * (size_t)slot + 2];
-        return sphere_roots(moving_center(q0, meta.w, q2, r.time), q0.w, r, t_min, t_max, t_out);
+    case RT_PRIM_SPHERE: case RT_PRIM_MOVING_SPHERE: {   // one sphere_roots for both kinds: only the centre differs
+        V3 c = v3(q0.x, q0.y, q0.z);
+        if (type == RT_PRIM_MOVING_SPHERE) c = moving_center(q0, meta.w, sc.slots[4 * (size_t)slot + 2], r.time);
+        return sphere_roots(c, q0.w, r, t_min, t_max, t_out);
     }
     case RT_PRIM_XY_RECT: case RT_PRIM_XZ_RECT: case RT_PRIM_YZ_RECT:
         return rect_test(type, q0, meta.w, r, t_min, t_max, t_out, &a, &b);
@@ -313,59 +312,73 @@ RT_DEV void consider(Hit &best, float t, int32_t id, int32_t slot) {
 }
 
 // Slab test in the traversal's own arithmetic (boxes are padded by the flattener, so this need
-// not follow aabb3.rs).  NaNs from 0*inf are ignored by fminf/fmaxf, which keeps it conservative.
-RT_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv, float t_min, float t_max, float *t_near) {
-    float tx0 = (lo.x - o.x) * inv.x, tx1 = (hi.x - o.x) * inv.x;
-    float ty0 = (lo.y - o.y) * inv.y, ty1 = (hi.y - o.y) * inv.y;
-    float tz0 = (lo.z - o.z) * inv.z, tz1 = (hi.z - o.z) * inv.z;
+// not follow aabb3.rs): t = lo*inv - o*inv as one fma; `inv` is finite (see traverse()).
+RT_DEV bool slab(V3 lo, V3 hi, V3 inv, V3 oi, float t_min, float t_max, float *t_near) {
+    float tx0 = __builtin_fmaf(lo.x, inv.x, -oi.x), tx1 = __builtin_fmaf(hi.x, inv.x, -oi.x);
+    float ty0 = __builtin_fmaf(lo.y, inv.y, -oi.y), ty1 = __builtin_fmaf(hi.y, inv.y, -oi.y);
+    float tz0 = __builtin_fmaf(lo.z, inv.z, -oi.z), tz1 = __builtin_fmaf(hi.z, inv.z, -oi.z);
     float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
     float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t_max));
     *t_near = tn;
     return tn <= tf * 1.0000004f;
 }
 
+// Next stack entry whose box can still hold a closer-or-equal hit, or RT_BVH_EMPTY.
+RT_DEV int32_t pop_ref(const uint2 *stack, uint32_t stride, uint32_t &sp, float best_t) {
+    while (sp != 0) {
+        --sp;
+        uint2 e = stack[sp * stride];
+        if (__uint_as_float(e.y) <= best_t) return (int32_t)e.x;
+    }
+    return RT_BVH_EMPTY;
+}
+
+// "while-while" traversal: every lane walks inner nodes until it stands on a leaf (or is done);
+// only then does the wave run the primitive tests, so node steps and leaf steps are not
+// serialised against each other inside one iteration.
 template <bool STATS>
 RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_id, Hit &best, uint2 *stack, uint32_t stride, Counters &cnt) {
     int32_t ref = sc.root_ref;
     if (ref == RT_BVH_EMPTY) return;
-    V3 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    // For the box tests only, a direction component below 1e-30 in magnitude is replaced by 1e-30:
+    // 1/d stays finite, so lo*inv - o*inv cannot turn into inf - inf and the slab keeps its sign.
+    float dx = fabsf(r.d.x) < 1.0e-30f ? 1.0e-30f : r.d.x;
+    float dy = fabsf(r.d.y) < 1.0e-30f ? 1.0e-30f : r.d.y;
+    float dz = fabsf(r.d.z) < 1.0e-30f ? 1.0e-30f : r.d.z;
+    V3 inv = v3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+    V3 oi = r.o * inv;
     uint32_t sp = 0;
     for (;;) {
-        if (ref >= 0) {
+        while (ref >= 0 && ref != RT_BVH_EMPTY) {
             const float4 *n = sc.nodes + 4 * (size_t)ref;
             float4 a = n[0], b = n[1], c = n[2], d = n[3];
             if (STATS) cnt.node_visits += 1;
             float tl, tr;
-            bool hl = slab(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), r.o, inv, t_min, best.t, &tl);
-            bool hr = slab(v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), r.o, inv, t_min, best.t, &tr);
+            bool hl = slab(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), inv, oi, t_min, best.t, &tl);
+            bool hr = slab(v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), inv, oi, t_min, best.t, &tr);
             int32_t rl = f2i(d.x), rr = f2i(d.y);
             if (hl && hr) {
                 bool left_first = tl <= tr;
-                int32_t far_ref = left_first ? rr : rl;
-                float far_t = left_first ? tr : tl;
-                stack[sp * stride] = make_uint2((uint32_t)far_ref, __float_as_uint(far_t));
+                stack[sp * stride] = make_uint2((uint32_t)(left_first ? rr : rl), __float_as_uint(left_first ? tr : tl));
                 ++sp;
                 ref = left_first ? rl : rr;
-                continue;
-            }
-            if (hl) { ref = rl; continue; }
-            if (hr) { ref = rr; continue; }
-        } else {
-            uint32_t code = (uint32_t)~ref;
-            uint32_t first = code >> 3, count = (code & 7u) + 1u;
-            for (uint32_t i = 0; i < count; ++i) {
-                float t;
-                int32_t id;
-                if (slot_hit<STATS>(sc, first + i, r, t_min, best.t, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)(first + i));
+            } else if (hl) {
+                ref = rl;
+            } else if (hr) {
+                ref = rr;
+            } else {
+                ref = pop_ref(stack, stride, sp, best.t);
             }
         }
-        // pop; entries whose box starts beyond the current best cannot contain a closer-or-equal hit
-        for (;;) {
-            if (sp == 0) return;
-            --sp;
-            uint2 e = stack[sp * stride];
-            if (__uint_as_float(e.y) <= best.t) { ref = (int32_t)e.x; break; }
+        if (ref == RT_BVH_EMPTY) return;
+        uint32_t code = (uint32_t)~ref;
+        uint32_t first = code >> 3, count = (code & 7u) + 1u;
+        for (uint32_t i = 0; i < count; ++i) {
+            float t;
+            int32_t id;
+            if (slot_hit<STATS>(sc, first + i, r, t_min, best.t, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)(first + i));
         }
+        ref = pop_ref(stack, stride, sp, best.t);
     }
 }
 
