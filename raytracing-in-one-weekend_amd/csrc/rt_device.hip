@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -282,7 +283,15 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
         d_out = static_cast<float4 *>(tmp_out);
         if (d_rays) d_rays = static_cast<uint32_t *>(tmp_rays);
     }
-    int tiles_x = (x1 - x0 + 15) / 16, tiles_y = (y1 - y0 + 15) / 16;
+    // lanes per pixel (sample sub-ranges): depends on spp_count only, so a tile and the full frame
+    // split a pixel's samples the same way
+    // measured on MI355X (profiles/r1/sub_range_sweep.txt): 8 lanes per pixel from 128 samples up, 4 from 8 up
+    int sub_log2 = p->spp_count >= 128 ? 3 : p->spp_count >= 8 ? 2 : p->spp_count >= 2 ? 1 : 0;
+    if (const char *e = getenv("RT_SUB_LOG2")) { int v = atoi(e); if (v >= 0 && v <= 6) sub_log2 = v; }   // tuning knob
+    a.sub_log2 = sub_log2;
+    int rb = 6 - sub_log2;
+    int tile_w = 2 << ((rb + 1) >> 1), tile_h = 2 << (rb >> 1);
+    int tiles_x = (x1 - x0 + tile_w - 1) / tile_w, tiles_y = (y1 - y0 + tile_h - 1) / tile_h;
     dim3 grid((unsigned)(tiles_x * tiles_y)), block(256);
     size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(uint2);
     hipError_t e = hipSuccess;

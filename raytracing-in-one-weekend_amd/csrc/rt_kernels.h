@@ -826,6 +826,7 @@ struct RenderArgs {
     float bg[3];
     uint32_t seed;
     int32_t x0, y0, x1, y1;
+    int32_t sub_log2;   // log2 of the lanes (sample sub-ranges) per pixel, 0..6
     rt_camera cam;
 };
 
@@ -856,27 +857,36 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// Block = 256 lanes = 2x2 wave tiles of 8x8 pixels.  Dynamic LDS = stack_depth * 256 * 8 bytes.
+// Block = 256 lanes = 2x2 wave tiles.  A wave covers 64/S pixels, each by S lanes that trace
+// disjoint, contiguous sub-ranges of the pixel's samples (S = 1 << a.sub_log2, chosen by the host
+// from spp_count).  Lanes of one pixel do statistically the same work, so the wave's lanes finish
+// together; the S partial sums are added in sub-range order by the first lane (shuffles, no
+// scratch memory, deterministic).  Dynamic LDS = stack_depth * 256 * 8 bytes.
 template <bool STATS>
 __global__ void __launch_bounds__(256) render_kernel(DScene sc, RenderArgs a, float4 *__restrict__ out, unsigned long long *stats,
                                                      uint32_t *pixel_rays) {
     extern __shared__ uint2 lds_stack[];
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
-    const int tiles_x = (a.x1 - a.x0 + 15) / 16;
+    const uint32_t rb = 6u - (uint32_t)a.sub_log2;          // log2(pixels per wave)
+    const uint32_t wx_log = (rb + 1u) >> 1, wy_log = rb >> 1;
+    const uint32_t pw = 1u << rb;
+    const uint32_t pi = lane & (pw - 1u), sub = lane >> rb;
+    const int tile_w = 2 << wx_log, tile_h = 2 << wy_log;
+    const int tiles_x = (a.x1 - a.x0 + tile_w - 1) / tile_w;
     const int bx = (int)(blockIdx.x % (uint32_t)tiles_x), by = (int)(blockIdx.x / (uint32_t)tiles_x);
-    const int x = a.x0 + bx * 16 + (int)(wave & 1u) * 8 + (int)(lane & 7u);
-    const int y = a.y0 + by * 16 + (int)(wave >> 1) * 8 + (int)(lane >> 3);
+    const int x = a.x0 + bx * tile_w + (int)((wave & 1u) << wx_log) + (int)(pi & ((1u << wx_log) - 1u));
+    const int y = a.y0 + by * tile_h + (int)((wave >> 1) << wy_log) + (int)(pi >> wx_log);
     uint2 *stack = lds_stack + tid;
     const uint32_t stride = blockDim.x;
     Counters cnt{};
-    bool inside = x < a.x1 && y < a.y1;
+    const bool inside = x < a.x1 && y < a.y1;
+    const uint32_t pixel = inside ? (uint32_t)y * (uint32_t)a.width + (uint32_t)x : 0u;
+    V3 sum = v3(0.0f, 0.0f, 0.0f);
     if (inside) {
-        const uint32_t pixel = (uint32_t)y * (uint32_t)a.width + (uint32_t)x;
         const V3 background = v3(a.bg[0], a.bg[1], a.bg[2]);
-        V3 sum = v3(0.0f, 0.0f, 0.0f);
-        int s = a.spp_begin;
-        const int s_end = a.spp_begin + a.spp_count;
+        int s = a.spp_begin + (int)(((int64_t)a.spp_count * (int64_t)sub) >> a.sub_log2);
+        const int s_end = a.spp_begin + (int)(((int64_t)a.spp_count * (int64_t)(sub + 1u)) >> a.sub_log2);
         bool alive = false;
         Path ps;
         rts::Rng rng;
@@ -894,14 +904,24 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, RenderArgs a, fl
             alive = bounce<STATS>(sc, ps, background, rng, stack, stride, cnt);
             if (!alive) sum = sum + ps.radiance;  // camera.rs:203: color + ray_color(...)
         }
+    }
+    // partial sums of the pixel's sub-ranges, in order (all 64 lanes take part in the shuffles)
+    V3 tot = sum;
+    uint32_t pix_rays = cnt.rays;
+    for (uint32_t j = 1; j < (1u << a.sub_log2); ++j) {
+        int src = (int)(pi + (j << rb));
+        tot.x += __shfl(sum.x, src, 64); tot.y += __shfl(sum.y, src, 64); tot.z += __shfl(sum.z, src, 64);
+        if (STATS) pix_rays += __shfl(cnt.rays, src, 64);
+    }
+    if (inside && sub == 0u) {
         float4 o = out[pixel];
-        o.x += sum.x; o.y += sum.y; o.z += sum.z; o.w += (float)a.spp_count;
+        o.x += tot.x; o.y += tot.y; o.z += tot.z; o.w += (float)a.spp_count;
         out[pixel] = o;
-        if (STATS && pixel_rays) pixel_rays[pixel] += cnt.rays;
+        if (STATS && pixel_rays) pixel_rays[pixel] += pix_rays;
     }
     if (STATS) {
         uint32_t vals[21];
-        vals[0] = inside ? (uint32_t)a.spp_count : 0u;
+        vals[0] = inside && sub == 0u ? (uint32_t)a.spp_count : 0u;
         vals[1] = cnt.rays; vals[2] = cnt.node_visits;
         for (int i = 0; i < 6; ++i) vals[3 + i] = cnt.prim_tests[i];
         vals[9] = cnt.medium_tests; vals[10] = cnt.light_pdf_evals;
