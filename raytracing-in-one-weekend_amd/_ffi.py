@@ -242,7 +242,7 @@ def hip_lib():
     global _hip
     if _hip is not None:
         return _hip
-    path = os.path.join(LIB_DIR, "librtiow_hip.so")
+    path = os.environ.get("RTIOW_HIP_LIB") or os.path.join(LIB_DIR, "librtiow_hip.so")   # env: kernel-tuning builds
     if not os.path.exists(path):
         raise ImportError("%s is missing: the HIP extension is required, there is no CPU fallback "
                           "(run __graft_entry__.build())" % path)

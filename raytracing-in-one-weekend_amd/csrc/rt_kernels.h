@@ -33,6 +33,15 @@ namespace rtk {
 #define RT_DEV __device__ __forceinline__
 #define RT_MAX_MEDIA 4
 #define RT_F32_MAX 3.40282347e+38f
+// render_kernel scheduling: traverse while at least NUM/DEN of the live lanes are walking; run a leaf
+// step once RT_LEAF_MIN lanes stand on a leaf (or nobody is on an inner node)
+#ifndef RT_TRAV_NUM
+#define RT_TRAV_NUM 1
+#define RT_TRAV_DEN 2
+#endif
+#ifndef RT_LEAF_MIN
+#define RT_LEAF_MIN 16
+#endif
 
 struct V3 {
     float x, y, z;
@@ -509,6 +518,111 @@ RT_DEV bool closest_hit(const DScene &sc, const Ray &r, float t_min, float t_max
     return any;
 }
 
+/* ------------------------------------------------------------------ resumable traversal (render kernel) */
+
+// The render kernel does not call closest_hit(): it keeps the traversal of every lane in this
+// struct and advances it one node or one leaf at a time, so the wave can decide when to traverse
+// and when to shade (see render_kernel).  The result is the same as closest_hit()'s: the steps,
+// the pruning and the fold are identical, only their interleaving with other lanes differs.
+struct Trav {
+    int32_t ref;        // current node (>= 0), leaf (< 0) or RT_BVH_EMPTY when finished
+    uint32_t sp;
+    Hit best;
+    int32_t floor_id;   // id of the last NaN candidate (see closest_hit), -1 if none
+    V3 inv, oi;
+};
+
+// world.hit() up to the point where the BVH walk starts.  Returns true if there is a walk to do.
+template <bool STATS>
+RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max, rts::Rng &rng, Trav &tv, Counters &cnt) {
+    float med_t[RT_MAX_MEDIA];
+    bool med_ok[RT_MAX_MEDIA];
+#pragma unroll
+    for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m) {
+        med_ok[m] = false; med_t[m] = 0.0f;
+        if (m < sc.n_media) med_ok[m] = medium_hit<STATS>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
+    }
+    tv.floor_id = -1; tv.sp = 0; tv.ref = RT_BVH_EMPTY;
+    if (!ray_is_finite(r)) {
+        closest_hit_exhaustive<STATS>(sc, r, t_min, t_max, med_t, med_ok, tv.best, cnt);
+        return false;
+    }
+    if (r.d.x == 0.0f || r.d.y == 0.0f || r.d.z == 0.0f)
+        for (uint32_t i = 0; i < sc.n_rects; ++i) {
+            float t; int32_t id;
+            if (slot_hit<STATS>(sc, sc.rects[i], r, t_min, t_max, &t, &id, cnt) && t != t && id > tv.floor_id) tv.floor_id = id;
+        }
+    tv.best.t = t_max; tv.best.id = -1; tv.best.slot = 0;
+    for (uint32_t i = 0; i < sc.always_count; ++i) {
+        float t; int32_t id;
+        uint32_t s = sc.always_begin + i;
+        if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)s);
+    }
+    if (sc.n_moving && !(r.time >= 0.0f && r.time <= 1.0f))
+        for (uint32_t i = 0; i < sc.n_moving; ++i) {
+            float t; int32_t id;
+            uint32_t s = sc.moving[i];
+            if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)s);
+        }
+#pragma unroll
+    for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m)
+        if (med_ok[m] && f2i(sc.media[2 * m + 1].z) > tv.floor_id) consider(tv.best, med_t[m], f2i(sc.media[2 * m + 1].z), -(int32_t)(m + 1));
+    if (sc.root_ref == RT_BVH_EMPTY) return false;
+    float dx = fabsf(r.d.x) < 1.0e-30f ? 1.0e-30f : r.d.x;
+    float dy = fabsf(r.d.y) < 1.0e-30f ? 1.0e-30f : r.d.y;
+    float dz = fabsf(r.d.z) < 1.0e-30f ? 1.0e-30f : r.d.z;
+    tv.inv = v3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+    tv.oi = r.o * tv.inv;
+    tv.ref = sc.root_ref;
+    return true;
+}
+
+template <bool STATS>
+RT_DEV void trav_node_step(const DScene &sc, float t_min, Trav &tv, uint2 *stack, uint32_t stride, Counters &cnt) {
+    const float4 *n = sc.nodes + 4 * (size_t)tv.ref;
+    float4 a = n[0], b = n[1], c = n[2], d = n[3];
+    if (STATS) cnt.node_visits += 1;
+    float tl, tr;
+    bool hl = slab(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), tv.inv, tv.oi, t_min, tv.best.t, &tl);
+    bool hr = slab(v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), tv.inv, tv.oi, t_min, tv.best.t, &tr);
+    int32_t rl = f2i(d.x), rr = f2i(d.y);
+    if (hl && hr) {
+        bool left_first = tl <= tr;
+        stack[tv.sp * stride] = make_uint2((uint32_t)(left_first ? rr : rl), __float_as_uint(left_first ? tr : tl));
+        ++tv.sp;
+        tv.ref = left_first ? rl : rr;
+    } else if (hl) {
+        tv.ref = rl;
+    } else if (hr) {
+        tv.ref = rr;
+    } else {
+        tv.ref = pop_ref(stack, stride, tv.sp, tv.best.t);
+    }
+}
+
+template <bool STATS>
+RT_DEV void trav_leaf_step(const DScene &sc, const Ray &r, float t_min, Trav &tv, const uint2 *stack, uint32_t stride, Counters &cnt) {
+    uint32_t code = (uint32_t)~tv.ref;
+    uint32_t first = code >> 3, count = (code & 7u) + 1u;
+    for (uint32_t i = 0; i < count; ++i) {
+        float t;
+        int32_t id;
+        if (slot_hit<STATS>(sc, first + i, r, t_min, tv.best.t, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)(first + i));
+    }
+    tv.ref = pop_ref(stack, stride, tv.sp, tv.best.t);
+}
+
+// After the walk: if nothing came after the last NaN candidate, that candidate is the hit.
+template <bool STATS>
+RT_DEV void finish_trace(const DScene &sc, const Ray &r, float t_min, float t_max, Trav &tv, Counters &cnt) {
+    if (tv.best.id >= 0 || tv.floor_id < 0) return;
+    for (uint32_t i = 0; i < sc.n_rects; ++i) {
+        float t; int32_t id;
+        uint32_t s = sc.rects[i];
+        if (slot_hit<false>(sc, s, r, t_min, t_max, &t, &id, cnt) && id == tv.floor_id) { tv.best.t = t; tv.best.id = id; tv.best.slot = (int32_t)s; }
+    }
+}
+
 /* ------------------------------------------------------------------ textures */
 
 RT_DEV float perlin_smooth(float t) { return t * t * (3.0f - 2.0f * t); }  // perlin.rs:60-62
@@ -715,13 +829,11 @@ struct Path {
     int depth;       // remaining depth (camera.rs:258)
 };
 
-// Returns true while the path continues.  camera.rs:253-309.
+// Everything ray_color does after world.hit() returned `best` (camera.rs:264-308).  Returns true
+// while the path continues (ps.ray is then the scattered ray and ps.depth is one less).
 template <bool STATS>
-RT_DEV bool bounce(const DScene &sc, Path &ps, V3 background, rts::Rng &rng, uint2 *stack, uint32_t stride, Counters &cnt) {
-    if (ps.depth <= 0) return false;  // contributes 0
-    if (STATS) cnt.rays += 1;
-    Hit best;
-    if (!closest_hit<STATS>(sc, ps.ray, 0.001f, INFINITY, true, rng, best, stack, stride, cnt)) {
+RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background, rts::Rng &rng, Counters &cnt) {
+    if (best.id < 0) {
         ps.radiance = ps.radiance + ps.throughput * background;
         return false;
     }
@@ -882,27 +994,68 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, RenderArgs a, fl
     Counters cnt{};
     const bool inside = x < a.x1 && y < a.y1;
     const uint32_t pixel = inside ? (uint32_t)y * (uint32_t)a.width + (uint32_t)x : 0u;
+    const V3 background = v3(a.bg[0], a.bg[1], a.bg[2]);
     V3 sum = v3(0.0f, 0.0f, 0.0f);
-    if (inside) {
-        const V3 background = v3(a.bg[0], a.bg[1], a.bg[2]);
-        int s = a.spp_begin + (int)(((int64_t)a.spp_count * (int64_t)sub) >> a.sub_log2);
-        const int s_end = a.spp_begin + (int)(((int64_t)a.spp_count * (int64_t)(sub + 1u)) >> a.sub_log2);
-        bool alive = false;
-        Path ps;
-        rts::Rng rng;
-        for (;;) {
-            if (!alive) {
-                if (s >= s_end) break;
-                rts::path_rng(rng, a.seed, pixel, (uint32_t)s);
-                ps.ray = camera_ray(sc, a, x, y, pixel, (uint32_t)s, rng);
-                ps.throughput = v3(1.0f, 1.0f, 1.0f);
-                ps.radiance = v3(0.0f, 0.0f, 0.0f);
-                ps.depth = a.max_depth;
-                ++s;
-                alive = true;
+    int s = a.spp_begin + (int)(((int64_t)a.spp_count * (int64_t)sub) >> a.sub_log2);
+    const int s_end = a.spp_begin + (int)(((int64_t)a.spp_count * (int64_t)(sub + 1u)) >> a.sub_log2);
+    // Per-lane state machine.  The wave alternates between two kinds of phases, chosen with
+    // ballots: a TRAVERSAL burst (lanes with a walk in progress take node / leaf steps while the
+    // others wait) and a SHADE phase (lanes whose walk has ended shade, start the next sample if
+    // the path is over, and begin the next walk).  A lane's own sequence of operations does not
+    // depend on the schedule, so results are the same as with one closest_hit() per bounce.
+    enum { ST_TRAV = 0, ST_SHADE = 1, ST_REGEN = 2, ST_DONE = 3 };
+    int st = (inside && s < s_end) ? ST_REGEN : ST_DONE;
+    Path ps;
+    ps.depth = 0;
+    rts::Rng rng{0, 1};
+    Trav tv;
+    tv.ref = RT_BVH_EMPTY; tv.sp = 0; tv.best.t = 0.0f; tv.best.id = -1; tv.best.slot = 0; tv.floor_id = -1;
+    tv.inv = v3(0.0f, 0.0f, 0.0f); tv.oi = tv.inv;
+    const float T_MIN = 0.001f, T_MAX = INFINITY;   // camera.rs:264
+    for (;;) {
+        const int n_trav = __popcll(__ballot(st == ST_TRAV));
+        const int n_wait = __popcll(__ballot(st == ST_SHADE || st == ST_REGEN));
+        const int alive = n_trav + n_wait;
+        if (alive == 0) break;
+        if (n_trav > 0 && (n_wait == 0 || n_trav * RT_TRAV_DEN >= alive * RT_TRAV_NUM)) {
+            int nt = n_trav;
+            do {
+                if (st == ST_TRAV && tv.ref >= 0) trav_node_step<STATS>(sc, T_MIN, tv, stack, stride, cnt);
+                const bool at_leaf = st == ST_TRAV && tv.ref < 0;
+                const unsigned long long m_leaf = __ballot(at_leaf);
+                const unsigned long long m_node = __ballot(st == ST_TRAV && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
+                if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
+                    if (at_leaf) trav_leaf_step<STATS>(sc, ps.ray, T_MIN, tv, stack, stride, cnt);
+                }
+                if (st == ST_TRAV && tv.ref == RT_BVH_EMPTY) {
+                    finish_trace<STATS>(sc, ps.ray, T_MIN, T_MAX, tv, cnt);
+                    st = ST_SHADE;
+                }
+                nt = __popcll(__ballot(st == ST_TRAV));
+            } while (nt > 0 && nt * RT_TRAV_DEN >= alive * RT_TRAV_NUM);
+        } else {
+            bool need_trace = false;
+            if (st == ST_SHADE) {
+                bool cont = shade_hit<STATS>(sc, ps, tv.best, background, rng, cnt);
+                if (cont && ps.depth > 0) need_trace = true;             // depth <= 0 contributes 0 (camera.rs:260)
+                else { sum = sum + ps.radiance; st = ST_REGEN; }         // camera.rs:203: color + ray_color(...)
             }
-            alive = bounce<STATS>(sc, ps, background, rng, stack, stride, cnt);
-            if (!alive) sum = sum + ps.radiance;  // camera.rs:203: color + ray_color(...)
+            if (st == ST_REGEN) {
+                if (s >= s_end) st = ST_DONE;
+                else {
+                    rts::path_rng(rng, a.seed, pixel, (uint32_t)s);
+                    ps.ray = camera_ray(sc, a, x, y, pixel, (uint32_t)s, rng);
+                    ps.throughput = v3(1.0f, 1.0f, 1.0f);
+                    ps.radiance = v3(0.0f, 0.0f, 0.0f);
+                    ps.depth = a.max_depth;
+                    ++s;
+                    if (ps.depth > 0) need_trace = true;
+                }
+            }
+            if (need_trace) {
+                if (STATS) cnt.rays += 1;
+                st = begin_trace<STATS>(sc, ps.ray, T_MIN, T_MAX, rng, tv, cnt) ? ST_TRAV : ST_SHADE;
+            }
         }
     }
     // partial sums of the pixel's sub-ranges, in order (all 64 lanes take part in the shuffles)
