@@ -144,6 +144,11 @@ def main():
                 "seed": rt.configs.SEED, "primitives": int(flat.desc.n_prims), "bvh_nodes": int(flat.desc.n_bvh_nodes)},
             "rays_per_step": total_rays, "paths_per_step": total_paths,
             "mpaths_per_s": total_paths * args.steps / elapsed / 1e6,
+            # lane occupancy per kernel phase (counting variant): lanes working / lanes issued
+            "phase_occupancy": {n: (round(l / s_, 4) if s_ else None) for n, l, s_ in zip(
+                ("node_step", "leaf_step", "shade", "path_start", "begin_trace"), st["phase_lanes"], st["phase_slots"])},
+            "phase_wave_runs_per_ray": {n: round(s_ / 64.0 / max(st["rays"], 1) * 64, 3) for n, s_ in zip(
+                ("node_step", "leaf_step", "shade", "path_start", "begin_trace"), st["phase_slots"])},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
                          "kernel": "rtk::render_kernel<false>", "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,

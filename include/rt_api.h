@@ -161,6 +161,10 @@ typedef struct rt_stats {
     uint64_t shades[5];        /* scatter calls by rtg_material_type                    */
     uint64_t tex_evals[4];     /* texture value() calls by rtg_texture_type             */
     uint64_t accepted_hits;    /* rays that found a hit                                 */
+    /* Lane occupancy of the render kernel's phases (0 node step, 1 leaf step, 2 shade, 3 path start,
+       4 begin-trace): phase_slots += 64 each time a wave runs the phase, phase_lanes += lanes working in it. */
+    uint64_t phase_lanes[5];
+    uint64_t phase_slots[5];
 } rt_stats;
 
 /* ------------------------------------------------------------------- entry points */

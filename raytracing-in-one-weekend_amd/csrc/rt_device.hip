@@ -283,18 +283,30 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
         d_out = static_cast<float4 *>(tmp_out);
         if (d_rays) d_rays = static_cast<uint32_t *>(tmp_rays);
     }
-    // lanes per pixel (sample sub-ranges): depends on spp_count only, so a tile and the full frame
-    // split a pixel's samples the same way
-    // measured on MI355X (profiles/r1/sub_range_sweep.txt): 8 lanes per pixel from 128 samples up, 4 from 8 up
+    // Pixels per wave (64 >> sub_log2): fewer pixels per wave = more waves for the same image, which is
+    // what a long render of a small image needs to fill 256 CUs.  Depends on spp_count only.
     int sub_log2 = p->spp_count >= 128 ? 3 : p->spp_count >= 8 ? 2 : p->spp_count >= 2 ? 1 : 0;
-    if (const char *e = getenv("RT_SUB_LOG2")) { int v = atoi(e); if (v >= 0 && v <= 6) sub_log2 = v; }   // tuning knob
-    a.sub_log2 = sub_log2;
+    if (const char *e = getenv("RT_SUB_LOG2")) { int v = atoi(e); if (v >= 0 && v <= 6) sub_log2 = v; }   // tuning knobs
+    int items = 512;                                   // queue length per wave and chunk
+    if (const char *e = getenv("RT_CHUNK_ITEMS")) { int v = atoi(e); if (v >= 64 && v <= 4096) items = v; }
     int rb = 6 - sub_log2;
+    int chunk = items >> rb;
+    if (chunk < 1) chunk = 1;
+    if (chunk > p->spp_count) chunk = p->spp_count;
+    a.sub_log2 = sub_log2;
+    a.chunk = chunk;
+    a.stack_depth = (int)ctx->stack_depth;
     int tile_w = 2 << ((rb + 1) >> 1), tile_h = 2 << (rb >> 1);
     int tiles_x = (x1 - x0 + tile_w - 1) / tile_w, tiles_y = (y1 - y0 + tile_h - 1) / tile_h;
     dim3 grid((unsigned)(tiles_x * tiles_y)), block(256);
-    size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(uint2);
+    size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(uint2) + (size_t)4 * 3 * sizeof(float) * ((size_t)chunk << rb);
+    if (lds > 160 * 1024) return fail(ctx, RT_E_INVALID, "LDS budget exceeded (%zu bytes)", lds);
     hipError_t e = hipSuccess;
+    if (lds > 64 * 1024) {   // above the default dynamic-LDS limit the kernel has to be told
+        e = p->collect_stats ? hipFuncSetAttribute((const void *)render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                             : hipFuncSetAttribute((const void *)render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(ctx, RT_E_HIP, "hipFuncSetAttribute(LDS %zu): %s", lds, hipGetErrorString(e));
+    }
     if (p->collect_stats) {
         e = hipMemsetAsync(ctx->d_stats, 0, 32 * sizeof(unsigned long long), stream);
         if (e == hipSuccess) hipLaunchKernelGGL(render_kernel<true>, grid, block, lds, stream, ctx->sc, a, d_out, ctx->d_stats, d_rays);
@@ -324,6 +336,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
         for (int i = 0; i < 5; ++i) stats->shades[i] = h_stats[11 + i];
         for (int i = 0; i < 4; ++i) stats->tex_evals[i] = h_stats[16 + i];
         stats->accepted_hits = h_stats[20];
+        for (int i = 0; i < 5; ++i) { stats->phase_lanes[i] = h_stats[21 + i]; stats->phase_slots[i] = h_stats[26 + i]; }
     }
     return RT_OK;
 }

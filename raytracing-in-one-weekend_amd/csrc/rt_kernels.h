@@ -105,7 +105,9 @@ struct DScene {
 
 struct Counters {  // only live in the STATS instantiation
     uint32_t rays, node_visits, prim_tests[6], medium_tests, light_pdf_evals, shades[5], tex_evals[4], accepted;
+    uint32_t phase_lanes[5], phase_slots[5];
 };
+enum { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_START = 3, PH_BEGIN = 4 };
 
 struct Hit {      // what the search tracks
     float t;
@@ -938,7 +940,9 @@ struct RenderArgs {
     float bg[3];
     uint32_t seed;
     int32_t x0, y0, x1, y1;
-    int32_t sub_log2;   // log2 of the lanes (sample sub-ranges) per pixel, 0..6
+    int32_t sub_log2;   // a wave owns 64 >> sub_log2 pixels (0..6)
+    int32_t chunk;      // samples per pixel per chunk (radiance slots in LDS: (64 >> sub_log2) * chunk per wave)
+    int32_t stack_depth;
     rt_camera cam;
 };
 
@@ -964,47 +968,61 @@ RT_DEV Ray camera_ray(const DScene &sc, const RenderArgs &a, int x, int y, uint3
     return r;
 }
 
+// Lane-occupancy telemetry; call where the wave is converged.
+template <bool STATS>
+RT_DEV void phase_count(Counters &cnt, int ph, bool active) {
+    if (STATS) {
+        const unsigned long long m = __ballot(active);
+        if (active) {
+            cnt.phase_lanes[ph] += 1;
+            if ((m & (0ull - m)) == (1ull << (threadIdx.x & 63u))) cnt.phase_slots[ph] += 64;
+        }
+    }
+}
+
 RT_DEV uint32_t wave_sum(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
 
-// Block = 256 lanes = 2x2 wave tiles.  A wave covers 64/S pixels, each by S lanes that trace
-// disjoint, contiguous sub-ranges of the pixel's samples (S = 1 << a.sub_log2, chosen by the host
-// from spp_count).  Lanes of one pixel do statistically the same work, so the wave's lanes finish
-// together; the S partial sums are added in sub-range order by the first lane (shuffles, no
-// scratch memory, deterministic).  Dynamic LDS = stack_depth * 256 * 8 bytes.
+// Block = 256 lanes = 2x2 wave tiles; a wave owns P = 64 >> a.sub_log2 pixels and all of their
+// samples, taken in chunks of a.chunk samples per pixel.
+//
+// Work distribution: the P * chunk pixel samples of a chunk form a queue that the wave's 64 lanes
+// drain together — a lane that needs a path takes the next queue index (ballot + prefix count on
+// a wave-uniform counter, no atomics).  Lanes therefore stay busy until the chunk is empty however
+// uneven the path lengths are; a lane is not tied to a pixel.  Every finished path stores its
+// radiance in the wave's LDS slot of that (pixel, sample); when the chunk is done, lane l < P adds
+// pixel l's slots IN SAMPLE ORDER to its running sum — exactly the reference's fold
+// (camera.rs:195-250), independent of which lane traced what and of the tile alignment.
+//
+// Dynamic LDS per block: stack_depth * 256 * 8 B (traversal stacks) + 4 * P * chunk * 12 B (radiance slots).
 template <bool STATS>
 __global__ void __launch_bounds__(256) render_kernel(DScene sc, RenderArgs a, float4 *__restrict__ out, unsigned long long *stats,
                                                      uint32_t *pixel_rays) {
     extern __shared__ uint2 lds_stack[];
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
-    const uint32_t rb = 6u - (uint32_t)a.sub_log2;          // log2(pixels per wave)
+    const uint32_t rb = 6u - (uint32_t)a.sub_log2;          // log2(P)
     const uint32_t wx_log = (rb + 1u) >> 1, wy_log = rb >> 1;
-    const uint32_t pw = 1u << rb;
-    const uint32_t pi = lane & (pw - 1u), sub = lane >> rb;
+    const uint32_t P = 1u << rb;
     const int tile_w = 2 << wx_log, tile_h = 2 << wy_log;
     const int tiles_x = (a.x1 - a.x0 + tile_w - 1) / tile_w;
     const int bx = (int)(blockIdx.x % (uint32_t)tiles_x), by = (int)(blockIdx.x / (uint32_t)tiles_x);
-    const int x = a.x0 + bx * tile_w + (int)((wave & 1u) << wx_log) + (int)(pi & ((1u << wx_log) - 1u));
-    const int y = a.y0 + by * tile_h + (int)((wave >> 1) << wy_log) + (int)(pi >> wx_log);
+    const int wave_x0 = a.x0 + bx * tile_w + (int)((wave & 1u) << wx_log);
+    const int wave_y0 = a.y0 + by * tile_h + (int)((wave >> 1) << wy_log);
     uint2 *stack = lds_stack + tid;
     const uint32_t stride = blockDim.x;
+    const uint32_t slots = P * (uint32_t)a.chunk;            // radiance slots of this wave
+    float *rad = reinterpret_cast<float *>(lds_stack + (size_t)a.stack_depth * 256u) + (size_t)wave * 3u * slots;
     Counters cnt{};
-    const bool inside = x < a.x1 && y < a.y1;
-    const uint32_t pixel = inside ? (uint32_t)y * (uint32_t)a.width + (uint32_t)x : 0u;
     const V3 background = v3(a.bg[0], a.bg[1], a.bg[2]);
+    // lane l < P is also the keeper of pixel l's sum
+    const int own_x = wave_x0 + (int)(lane & ((1u << wx_log) - 1u)), own_y = wave_y0 + (int)((lane & (P - 1u)) >> wx_log);
+    const bool own = lane < P && own_x < a.x1 && own_y < a.y1;
     V3 sum = v3(0.0f, 0.0f, 0.0f);
-    int s = a.spp_begin + (int)(((int64_t)a.spp_count * (int64_t)sub) >> a.sub_log2);
-    const int s_end = a.spp_begin + (int)(((int64_t)a.spp_count * (int64_t)(sub + 1u)) >> a.sub_log2);
-    // Per-lane state machine.  The wave alternates between two kinds of phases, chosen with
-    // ballots: a TRAVERSAL burst (lanes with a walk in progress take node / leaf steps while the
-    // others wait) and a SHADE phase (lanes whose walk has ended shade, start the next sample if
-    // the path is over, and begin the next walk).  A lane's own sequence of operations does not
-    // depend on the schedule, so results are the same as with one closest_hit() per bounce.
+    uint32_t paths = 0;
     enum { ST_TRAV = 0, ST_SHADE = 1, ST_REGEN = 2, ST_DONE = 3 };
-    int st = (inside && s < s_end) ? ST_REGEN : ST_DONE;
     Path ps;
     ps.depth = 0;
     rts::Rng rng{0, 1};
@@ -1012,76 +1030,109 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, RenderArgs a, fl
     tv.ref = RT_BVH_EMPTY; tv.sp = 0; tv.best.t = 0.0f; tv.best.id = -1; tv.best.slot = 0; tv.floor_id = -1;
     tv.inv = v3(0.0f, 0.0f, 0.0f); tv.oi = tv.inv;
     const float T_MIN = 0.001f, T_MAX = INFINITY;   // camera.rs:264
-    for (;;) {
-        const int n_trav = __popcll(__ballot(st == ST_TRAV));
-        const int n_wait = __popcll(__ballot(st == ST_SHADE || st == ST_REGEN));
-        const int alive = n_trav + n_wait;
-        if (alive == 0) break;
-        if (n_trav > 0 && (n_wait == 0 || n_trav * RT_TRAV_DEN >= alive * RT_TRAV_NUM)) {
-            int nt = n_trav;
-            do {
-                if (st == ST_TRAV && tv.ref >= 0) trav_node_step<STATS>(sc, T_MIN, tv, stack, stride, cnt);
-                const bool at_leaf = st == ST_TRAV && tv.ref < 0;
-                const unsigned long long m_leaf = __ballot(at_leaf);
-                const unsigned long long m_node = __ballot(st == ST_TRAV && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
-                if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
-                    if (at_leaf) trav_leaf_step<STATS>(sc, ps.ray, T_MIN, tv, stack, stride, cnt);
+    const int s_end = a.spp_begin + a.spp_count;
+    for (int chunk_begin = a.spp_begin; chunk_begin < s_end; chunk_begin += a.chunk) {
+        const uint32_t c_len = (uint32_t)min(a.chunk, s_end - chunk_begin);
+        const uint32_t n_items = c_len << rb;
+        uint32_t next_q = 0;          // wave-uniform queue head
+        uint32_t q = 0;               // the item this lane is working on
+        uint32_t path_rays = 0, pixel = 0;
+        int st = ST_REGEN;
+        for (;;) {
+            const int n_trav = __popcll(__ballot(st == ST_TRAV));
+            const int n_wait = __popcll(__ballot(st == ST_SHADE || st == ST_REGEN));
+            const int alive = n_trav + n_wait;
+            if (alive == 0) break;
+            if (n_trav > 0 && (n_wait == 0 || n_trav * RT_TRAV_DEN >= alive * RT_TRAV_NUM)) {
+                int nt = n_trav;
+                do {
+                    phase_count<STATS>(cnt, PH_NODE, st == ST_TRAV && tv.ref >= 0);
+                    if (st == ST_TRAV && tv.ref >= 0) trav_node_step<STATS>(sc, T_MIN, tv, stack, stride, cnt);
+                    const bool at_leaf = st == ST_TRAV && tv.ref < 0;
+                    const unsigned long long m_leaf = __ballot(at_leaf);
+                    const unsigned long long m_node = __ballot(st == ST_TRAV && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
+                    if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
+                        phase_count<STATS>(cnt, PH_LEAF, at_leaf);
+                        if (at_leaf) trav_leaf_step<STATS>(sc, ps.ray, T_MIN, tv, stack, stride, cnt);
+                    }
+                    if (st == ST_TRAV && tv.ref == RT_BVH_EMPTY) {
+                        finish_trace<STATS>(sc, ps.ray, T_MIN, T_MAX, tv, cnt);
+                        st = ST_SHADE;
+                    }
+                    nt = __popcll(__ballot(st == ST_TRAV));
+                } while (nt > 0 && nt * RT_TRAV_DEN >= alive * RT_TRAV_NUM);
+            } else {
+                bool need_trace = false;
+                phase_count<STATS>(cnt, PH_SHADE, st == ST_SHADE);
+                if (st == ST_SHADE) {
+                    bool cont = shade_hit<STATS>(sc, ps, tv.best, background, rng, cnt);
+                    if (cont && ps.depth > 0) need_trace = true;             // depth <= 0 contributes 0 (camera.rs:260)
+                    else {                                                   // path over: park its radiance in its slot
+                        rad[q] = ps.radiance.x; rad[slots + q] = ps.radiance.y; rad[2u * slots + q] = ps.radiance.z;
+                        if (STATS && pixel_rays) atomicAdd(&pixel_rays[pixel], path_rays);
+                        st = ST_REGEN;
+                    }
                 }
-                if (st == ST_TRAV && tv.ref == RT_BVH_EMPTY) {
-                    finish_trace<STATS>(sc, ps.ray, T_MIN, T_MAX, tv, cnt);
-                    st = ST_SHADE;
+                // take the next queue items: lanes in ST_REGEN get consecutive indices
+                const unsigned long long m_regen = __ballot(st == ST_REGEN);
+                phase_count<STATS>(cnt, PH_START, st == ST_REGEN);
+                if (st == ST_REGEN) {
+                    q = next_q + (uint32_t)__popcll(m_regen & ((1ull << lane) - 1ull));
+                    if (q >= n_items) st = ST_DONE;
+                    else {
+                        const uint32_t pl = q & (P - 1u), k = q >> rb;       // pixel within the wave tile, sample within the chunk
+                        const int x = wave_x0 + (int)(pl & ((1u << wx_log) - 1u)), y = wave_y0 + (int)(pl >> wx_log);
+                        if (x < a.x1 && y < a.y1) {
+                            const uint32_t s = (uint32_t)chunk_begin + k;
+                            pixel = (uint32_t)y * (uint32_t)a.width + (uint32_t)x;
+                            rts::path_rng(rng, a.seed, pixel, s);
+                            ps.ray = camera_ray(sc, a, x, y, pixel, s, rng);
+                            ps.throughput = v3(1.0f, 1.0f, 1.0f);
+                            ps.radiance = v3(0.0f, 0.0f, 0.0f);
+                            ps.depth = a.max_depth;
+                            path_rays = 0;
+                            paths += 1;
+                            if (ps.depth > 0) need_trace = true;
+                            else { rad[q] = 0.0f; rad[slots + q] = 0.0f; rad[2u * slots + q] = 0.0f; }
+                        }   // an item outside the image is dropped; the lane asks again in the next phase
+                    }
                 }
-                nt = __popcll(__ballot(st == ST_TRAV));
-            } while (nt > 0 && nt * RT_TRAV_DEN >= alive * RT_TRAV_NUM);
-        } else {
-            bool need_trace = false;
-            if (st == ST_SHADE) {
-                bool cont = shade_hit<STATS>(sc, ps, tv.best, background, rng, cnt);
-                if (cont && ps.depth > 0) need_trace = true;             // depth <= 0 contributes 0 (camera.rs:260)
-                else { sum = sum + ps.radiance; st = ST_REGEN; }         // camera.rs:203: color + ray_color(...)
-            }
-            if (st == ST_REGEN) {
-                if (s >= s_end) st = ST_DONE;
-                else {
-                    rts::path_rng(rng, a.seed, pixel, (uint32_t)s);
-                    ps.ray = camera_ray(sc, a, x, y, pixel, (uint32_t)s, rng);
-                    ps.throughput = v3(1.0f, 1.0f, 1.0f);
-                    ps.radiance = v3(0.0f, 0.0f, 0.0f);
-                    ps.depth = a.max_depth;
-                    ++s;
-                    if (ps.depth > 0) need_trace = true;
+                next_q += (uint32_t)__popcll(m_regen);
+                phase_count<STATS>(cnt, PH_BEGIN, need_trace);
+                if (need_trace) {
+                    if (STATS) { cnt.rays += 1; path_rays += 1; }
+                    st = begin_trace<STATS>(sc, ps.ray, T_MIN, T_MAX, rng, tv, cnt) ? ST_TRAV : ST_SHADE;
                 }
-            }
-            if (need_trace) {
-                if (STATS) cnt.rays += 1;
-                st = begin_trace<STATS>(sc, ps.ray, T_MIN, T_MAX, rng, tv, cnt) ? ST_TRAV : ST_SHADE;
             }
         }
+        // the fold of camera.rs:195-250 for this chunk: pixel `lane`, samples in order
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (own)
+            for (uint32_t k = 0; k < c_len; ++k) {
+                const uint32_t i = (k << rb) + lane;
+                sum.x += rad[i]; sum.y += rad[slots + i]; sum.z += rad[2u * slots + i];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    // partial sums of the pixel's sub-ranges, in order (all 64 lanes take part in the shuffles)
-    V3 tot = sum;
-    uint32_t pix_rays = cnt.rays;
-    for (uint32_t j = 1; j < (1u << a.sub_log2); ++j) {
-        int src = (int)(pi + (j << rb));
-        tot.x += __shfl(sum.x, src, 64); tot.y += __shfl(sum.y, src, 64); tot.z += __shfl(sum.z, src, 64);
-        if (STATS) pix_rays += __shfl(cnt.rays, src, 64);
-    }
-    if (inside && sub == 0u) {
-        float4 o = out[pixel];
-        o.x += tot.x; o.y += tot.y; o.z += tot.z; o.w += (float)a.spp_count;
-        out[pixel] = o;
-        if (STATS && pixel_rays) pixel_rays[pixel] += pix_rays;
+    if (own) {
+        const uint32_t opix = (uint32_t)own_y * (uint32_t)a.width + (uint32_t)own_x;
+        float4 o = out[opix];
+        o.x += sum.x; o.y += sum.y; o.z += sum.z; o.w += (float)a.spp_count;
+        out[opix] = o;
     }
     if (STATS) {
-        uint32_t vals[21];
-        vals[0] = inside && sub == 0u ? (uint32_t)a.spp_count : 0u;
+        uint32_t vals[31];
+        for (int i = 0; i < 5; ++i) { vals[21 + i] = cnt.phase_lanes[i]; vals[26 + i] = cnt.phase_slots[i]; }
+        vals[0] = paths;
         vals[1] = cnt.rays; vals[2] = cnt.node_visits;
         for (int i = 0; i < 6; ++i) vals[3 + i] = cnt.prim_tests[i];
         vals[9] = cnt.medium_tests; vals[10] = cnt.light_pdf_evals;
         for (int i = 0; i < 5; ++i) vals[11 + i] = cnt.shades[i];
         for (int i = 0; i < 4; ++i) vals[16 + i] = cnt.tex_evals[i];
         vals[20] = cnt.accepted;
-        for (int i = 0; i < 21; ++i) {
+        for (int i = 0; i < 31; ++i) {
             uint32_t w = wave_sum(vals[i]);
             if (lane == 0 && w) atomicAdd(&stats[i], (unsigned long long)w);
         }

@@ -8,5 +8,5 @@ done
 python3 - <<PY
 import json
 for l in open("gpurun_out/bench_all_$TAG.jsonl"):
-    d=json.loads(l); print(d["config"]["workload"][:34], "Mrays/s %.0f"%d["value"], "Mpaths/s %.0f"%d["mpaths_per_s"], "ms %.2f"%d["roofline"]["kernel_ms"], "TF %.2f"%d["roofline"]["achieved"])
+    d=json.loads(l); print(d["config"]["workload"][:34], "Mrays/s %.0f"%d["value"], "Mpaths/s %.0f"%d["mpaths_per_s"], "ms %.2f"%d["roofline"]["kernel_ms"], "TF %.2f"%d["roofline"]["achieved"], "occ", d.get("phase_occupancy"), "runs/ray", d.get("phase_wave_runs_per_ray"))
 PY
