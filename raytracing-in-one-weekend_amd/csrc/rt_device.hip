@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "rt_kernels.h"
+#include "rt_wavefront.h"
 
 using namespace rtk;
 
@@ -28,6 +29,12 @@ struct rt_ctx {
     uint32_t stack_depth = 1;
     unsigned long long *d_stats = nullptr;  // 32 counters
     hipDeviceProp_t prop{};
+    // wavefront workspace (grown on demand, kept until rt_destroy)
+    void *wf_pool = nullptr;      size_t wf_pool_entries = 0;   // 2 buffers x 6 arrays x entries x 16 B
+    float4 *wf_samples = nullptr; size_t wf_samples_entries = 0;
+    WfCounters *wf_ctr = nullptr;                               // ring + status words behind it
+    uint32_t *wf_host_status = nullptr;                         // pinned, 2 x 4 words
+    hipEvent_t wf_event[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -75,6 +82,125 @@ int set_device(rt_ctx *ctx) {
     return RT_OK;
 }
 
+size_t env_size(const char *name, size_t dflt, size_t lo, size_t hi) {
+    if (const char *e = getenv(name)) {
+        long long v = atoll(e);
+        if (v >= (long long)lo && v <= (long long)hi) return (size_t)v;
+    }
+    return dflt;
+}
+
+PathQ pool_buffer(rt_ctx *ctx, int which) {
+    float4 *base = static_cast<float4 *>(ctx->wf_pool) + (size_t)which * 6 * ctx->wf_pool_entries;
+    PathQ q;
+    q.ray_o = base; q.ray_d = base + ctx->wf_pool_entries; q.thr = base + 2 * ctx->wf_pool_entries;
+    q.rad = base + 3 * ctx->wf_pool_entries; q.rng = base + 4 * ctx->wf_pool_entries; q.hit = base + 5 * ctx->wf_pool_entries;
+    return q;
+}
+
+// The streaming pipeline of rt_wavefront.h for one rt_render call.  Samples are rendered in
+// batches that fit the sample buffer; within a batch the host enqueues iterations
+// (traverse, shade, generate) eight at a time and looks at the pool's status two groups behind,
+// so the GPU always has work queued while the host decides whether the pool has drained.
+template <bool STATS>
+int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p, float4 *d_out, uint32_t *d_rays, hipStream_t stream) {
+    const uint32_t tiles_x = (uint32_t)(a.x1 - a.x0 + 7) / 8u, tiles_y = (uint32_t)(a.y1 - a.y0 + 7) / 8u;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    const size_t per_sample = (size_t)n_tiles * 64u;                                    // items per sample of the window
+    const size_t cap_entries = env_size("RT_WF_SAMPLES_MB", 8192, 1, 262144) * (1024 * 1024 / 16);
+    if (per_sample > cap_entries || per_sample >= (1ull << 31)) return fail(ctx, RT_E_OOM, "window of %u tiles does not fit the sample buffer", n_tiles);
+    size_t spp_batch_max = cap_entries / per_sample;
+    if (spp_batch_max * per_sample >= (1ull << 32)) spp_batch_max = ((1ull << 32) - 1) / per_sample;
+    if (spp_batch_max > (size_t)a.spp_count) spp_batch_max = (size_t)a.spp_count;
+    const size_t pool_want = (size_t)1 << env_size("RT_WF_POOL_LOG2", 22, 14, 26);
+    // workspace
+    const size_t need_samples = spp_batch_max * per_sample;
+    if (ctx->wf_samples_entries < need_samples) {
+        if (ctx->wf_samples) { (void)hipStreamSynchronize(stream); (void)hipFree(ctx->wf_samples); ctx->wf_samples = nullptr; ctx->wf_samples_entries = 0; }
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->wf_samples, need_samples * 16));
+        ctx->wf_samples_entries = need_samples;
+    }
+    const size_t shard_q = (size_t)RT_WF_SHARDS * 256;    // pool sizes are multiples of this
+    size_t pool = need_samples < pool_want ? (need_samples + shard_q - 1) / shard_q * shard_q : pool_want;
+    if (ctx->wf_pool_entries < pool) {
+        if (ctx->wf_pool) { (void)hipStreamSynchronize(stream); (void)hipFree(ctx->wf_pool); ctx->wf_pool = nullptr; ctx->wf_pool_entries = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->wf_pool, pool * 2 * 6 * 16));
+        ctx->wf_pool_entries = pool;
+    }
+    if (!ctx->wf_ctr) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->wf_ctr, (RT_WF_RING + 1) * sizeof(WfCounters)));   // ring + one block for the status words
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->wf_host_status, 2 * 4 * sizeof(uint32_t), hipHostMallocDefault));
+        for (hipEvent_t &ev : ctx->wf_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    uint32_t *d_status = reinterpret_cast<uint32_t *>(ctx->wf_ctr + RT_WF_RING);
+    const PathQ Q[2] = {pool_buffer(ctx, 0), pool_buffer(ctx, 1)};
+    const bool has_bvh = ctx->sc.root_ref != RT_BVH_EMPTY;
+    const size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(uint2);
+    if (lds > 160 * 1024) return fail(ctx, RT_E_INVALID, "LDS budget exceeded (%zu bytes)", lds);
+    if (lds > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute((const void *)wf_traverse_kernel<STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_traverse_kernel<STATS>, 256, lds));
+    {   // the runtime's answer may assume the 64 KB per-workgroup LDS limit; gfx950 has 160 KB per CU
+        hipFuncAttributes fa{};
+        HIP_TRY(ctx, hipFuncGetAttributes(&fa, (const void *)wf_traverse_kernel<STATS>));
+        int regs = fa.numRegs > 0 ? (fa.numRegs + 7) / 8 * 8 : 128;
+        int by_regs = 512 / regs > 8 ? 8 : 512 / regs;
+        int by_lds = lds ? (int)((160 * 1024) / lds) : 8;
+        int mine = by_regs < by_lds ? by_regs : by_lds;
+        if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] traverse: numRegs %d lds %zu runtime per_cu %d, computed %d\n", fa.numRegs, lds, per_cu, mine);
+        if (mine > per_cu) per_cu = mine;
+        per_cu = (int)env_size("RT_WF_TRAV_BLOCKS", (size_t)per_cu, 1, 16);
+    }
+    if (per_cu < 1) per_cu = 1;
+    const unsigned trav_blocks = ((unsigned)(per_cu * ctx->prop.multiProcessorCount) + RT_WF_SHARDS - 1) / RT_WF_SHARDS * RT_WF_SHARDS;
+    unsigned long long *d_stats = STATS ? ctx->d_stats : nullptr;
+    if (STATS) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 32 * sizeof(unsigned long long), stream));
+
+    WfArgs w{};
+    w.a = a;
+    w.tiles_x = tiles_x; w.n_tiles = n_tiles;
+    for (int32_t s0 = 0; s0 < a.spp_count; s0 += (int32_t)spp_batch_max) {
+        w.spp_batch = (uint32_t)((size_t)(a.spp_count - s0) < spp_batch_max ? (size_t)(a.spp_count - s0) : spp_batch_max);
+        w.sample0 = (uint32_t)(a.spp_begin + s0);
+        w.n_items = (uint32_t)(per_sample * w.spp_batch);
+        const size_t items_up = ((size_t)w.n_items + shard_q - 1) / shard_q * shard_q;
+        w.pool = (uint32_t)(items_up < ctx->wf_pool_entries ? items_up : ctx->wf_pool_entries);
+        if (w.pool > pool_want) w.pool = (uint32_t)pool_want;
+        w.cap = w.pool / RT_WF_SHARDS;
+        const unsigned pool_blocks = w.pool / 256u;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->wf_ctr, 0, (RT_WF_RING + 1) * sizeof(WfCounters), stream));
+        ctx->wf_host_status[0] = ctx->wf_host_status[4] = 1u;   // "not drained"
+        ctx->wf_host_status[1] = ctx->wf_host_status[5] = 0u;
+        uint32_t it = 0;
+        hipLaunchKernelGGL(wf_generate_kernel<STATS>, dim3(pool_blocks), dim3(256), 0, stream, ctx->sc, w, Q[1], ctx->wf_ctr, it,
+                           ctx->wf_samples, d_status, d_stats, d_rays);
+        bool drained = false;
+        for (uint32_t group = 0; !drained; ++group) {
+            if (group >= 2) {   // look at the status copied after group - 2
+                HIP_TRY(ctx, hipEventSynchronize(ctx->wf_event[group & 1]));
+                const uint32_t *hs = ctx->wf_host_status + 4 * (group & 1);
+                if (hs[0] == 0u && hs[1] == w.n_items) { drained = true; break; }
+                if (p->cancel && *p->cancel) { (void)hipStreamSynchronize(stream); return fail(ctx, RT_E_CANCELLED, "cancelled"); }
+            }
+            for (int k = 0; k < 8; ++k) {
+                ++it;
+                const PathQ &cur = Q[it & 1], &nxt = Q[(it + 1) & 1];
+                if (has_bvh) hipLaunchKernelGGL(wf_traverse_kernel<STATS>, dim3(trav_blocks), dim3(256), lds, stream, ctx->sc, cur, ctx->wf_ctr, it, w.cap, d_stats);
+                hipLaunchKernelGGL(wf_shade_kernel<STATS>, dim3(pool_blocks), dim3(256), 0, stream, ctx->sc, w, cur, nxt, ctx->wf_ctr, it,
+                                   ctx->wf_samples, d_stats, d_rays);
+                hipLaunchKernelGGL(wf_generate_kernel<STATS>, dim3(pool_blocks), dim3(256), 0, stream, ctx->sc, w, nxt, ctx->wf_ctr, it,
+                                   ctx->wf_samples, d_status, d_stats, d_rays);
+            }
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host_status + 4 * (group & 1), d_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->wf_event[group & 1], stream));
+        }
+        hipLaunchKernelGGL(wf_fold_kernel, dim3((n_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, w, ctx->wf_samples, d_out);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -114,6 +240,11 @@ void rt_destroy(rt_ctx *ctx) {
     free_all(ctx->scene_allocs);
     free_all(ctx->sampler_allocs);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->wf_pool) (void)hipFree(ctx->wf_pool);
+    if (ctx->wf_samples) (void)hipFree(ctx->wf_samples);
+    if (ctx->wf_ctr) (void)hipFree(ctx->wf_ctr);
+    if (ctx->wf_host_status) (void)hipHostFree(ctx->wf_host_status);
+    for (hipEvent_t ev : ctx->wf_event) if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -283,6 +414,17 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
         d_out = static_cast<float4 *>(tmp_out);
         if (d_rays) d_rays = static_cast<uint32_t *>(tmp_rays);
     }
+    const char *pipe = getenv("RT_PIPELINE");
+    const bool wavefront = !(pipe && strcmp(pipe, "mega") == 0);
+    if (wavefront) {
+        int rc = p->collect_stats ? render_wavefront<true>(ctx, a, p, d_out, d_rays, stream) : render_wavefront<false>(ctx, a, p, d_out, d_rays, stream);
+        if (rc != RT_OK) {
+            (void)hipStreamSynchronize(stream);
+            if (tmp_out) (void)hipFree(tmp_out);
+            if (tmp_rays) (void)hipFree(tmp_rays);
+            return rc;
+        }
+    }
     // Pixels per wave (64 >> sub_log2): fewer pixels per wave = more waves for the same image, which is
     // what a long render of a small image needs to fill 256 CUs.  Depends on spp_count only.
     int sub_log2 = p->spp_count >= 128 ? 3 : p->spp_count >= 8 ? 2 : p->spp_count >= 2 ? 1 : 0;
@@ -307,7 +449,9 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
                              : hipFuncSetAttribute((const void *)render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(ctx, RT_E_HIP, "hipFuncSetAttribute(LDS %zu): %s", lds, hipGetErrorString(e));
     }
-    if (p->collect_stats) {
+    if (wavefront) {
+        // already enqueued above
+    } else if (p->collect_stats) {
         e = hipMemsetAsync(ctx->d_stats, 0, 32 * sizeof(unsigned long long), stream);
         if (e == hipSuccess) hipLaunchKernelGGL(render_kernel<true>, grid, block, lds, stream, ctx->sc, a, d_out, ctx->d_stats, d_rays);
     } else {

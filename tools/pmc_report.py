@@ -1,20 +1,30 @@
-"""Summarise gpurun_out/pmc_TAG_{a,b}: counters of rtk::render_kernel<false> + derived ratios."""
-import collections, csv, glob, json, sys
+"""Summarise gpurun_out/pmc_TAG_{a,b}: SQ counters per render-path kernel + derived ratios.
+usage: pmc_report.py TAG [out.json]"""
+import collections, csv, glob, json, re, sys
 tag = sys.argv[1]
-agg = collections.defaultdict(float); meta = {}
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); meta = {}; calls = collections.Counter()
 for part in "ab":
     for f in glob.glob("gpurun_out/pmc_%s_%s/*/*counter_collection.csv" % (tag, part)):
         for r in csv.DictReader(open(f)):
-            if "render_kernel<false>" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]] += float(r["Counter_Value"])
-                meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+            m = re.search(r"rtk::(\w+)<false>|rtk::(wf_fold_kernel)", r["Kernel_Name"])
+            if not m: continue
+            k = m.group(1) or m.group(2)
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "SQ_WAVES": calls[k] += 1
+            meta[k] = {x: r[x] for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
 b = json.load(open("gpurun_out/pmc_%s_a.json" % tag))
 rays = b["rays_per_step"]
-d = {"workload": b["config"]["workload"], "dispatch": meta, "counters": dict(agg), "rays": rays,
-     "valu_wave_insts_per_ray_x64": agg["SQ_INSTS_VALU"] * 64 / rays,
-     "lane_utilisation_pct": 100 * agg["SQ_THREAD_CYCLES_VALU"] / (agg["SQ_ACTIVE_INST_VALU"] * 64) if agg["SQ_ACTIVE_INST_VALU"] else None,
-     "valu_share_of_wave_cycles_pct": 100 * agg["SQ_ACTIVE_INST_VALU"] / agg["SQ_WAVE_CYCLES"] if agg["SQ_WAVE_CYCLES"] else None,
-     "wait_inst_share_pct": 100 * agg["SQ_WAIT_INST_ANY"] / agg["SQ_WAVE_CYCLES"] if agg["SQ_WAVE_CYCLES"] else None,
-     "kernel_ms_profiled": b["roofline"]["kernel_ms"]}
-json.dump(d, open(sys.argv[2], "w"), indent=1) if len(sys.argv) > 2 else None
-print(json.dumps(d, indent=1))
+out = {"workload": b["config"]["workload"], "rays": rays, "kernels": {}}
+for k, a in agg.items():
+    d = {"dispatches": calls[k], "dispatch": meta[k], "counters": dict(a),
+         "valu_lane_slots_per_ray": a["SQ_INSTS_VALU"] * 64 / rays,
+         "lane_utilisation_pct": 100 * a["SQ_THREAD_CYCLES_VALU"] / (a["SQ_ACTIVE_INST_VALU"] * 64) if a["SQ_ACTIVE_INST_VALU"] else None,
+         # SQ_BUSY_CYCLES is summed over 32 shader engines; 1024 SIMDs issue one wave64 VALU op per 4 cycles
+         "valu_pipe_busy_pct": 100 * a["SQ_INSTS_VALU"] * 4 / (a["SQ_BUSY_CYCLES"] / 32 * 1024) if a["SQ_BUSY_CYCLES"] else None,
+         "waves_per_simd_avg": a["SQ_WAVE_CYCLES"] * 4 / (a["SQ_BUSY_CYCLES"] / 32 * 1024) if a["SQ_BUSY_CYCLES"] else None,
+         "wait_inst_share_pct": 100 * a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"] if a["SQ_WAVE_CYCLES"] else None,
+         "busy_ms": a["SQ_BUSY_CYCLES"] / 32 / 2.4e6}
+    out["kernels"][k] = d
+if len(sys.argv) > 2: json.dump(out, open(sys.argv[2], "w"), indent=1)
+for k, d in out["kernels"].items():
+    print(k, {x: (round(v, 2) if isinstance(v, float) else v) for x, v in d.items() if x not in ("counters", "dispatch")}, "VGPR", d["dispatch"]["VGPR_Count"], "LDS", d["dispatch"]["LDS_Block_Size"])
