@@ -27,12 +27,13 @@ struct rt_ctx {
     DScene sc{};
     bool have_scene = false, have_sampler = false;
     uint32_t stack_depth = 1;
-    unsigned long long *d_stats = nullptr;  // 32 counters
+    unsigned long long *d_stats = nullptr;  // 64 counters
     hipDeviceProp_t prop{};
     // wavefront workspace (grown on demand, kept until rt_destroy)
-    void *wf_pool = nullptr;      size_t wf_pool_entries = 0;   // 2 buffers x 6 arrays x entries x 16 B
+    void *wf_pool = nullptr;      size_t wf_pool_entries = 0;   // 2 buffers x entries x 72 B
     float4 *wf_samples = nullptr; size_t wf_samples_entries = 0;
     WfCounters *wf_ctr = nullptr;                               // ring + status words behind it
+    StackEntry *wf_ovf = nullptr;  size_t wf_ovf_entries = 0;      // traversal stack overflow (entries beyond the LDS part)
     uint32_t *wf_host_status = nullptr;                         // pinned, 2 x 4 words
     hipEvent_t wf_event[2] = {nullptr, nullptr};
 };
@@ -90,12 +91,23 @@ size_t env_size(const char *name, size_t dflt, size_t lo, size_t hi) {
     return dflt;
 }
 
+constexpr size_t kEntryBytes = 72;   // rt_wavefront.h: 4 float4 + 1 float2 per pool entry
+
 PathQ pool_buffer(rt_ctx *ctx, int which) {
-    float4 *base = static_cast<float4 *>(ctx->wf_pool) + (size_t)which * 6 * ctx->wf_pool_entries;
+    const size_t n = ctx->wf_pool_entries;
+    char *base = static_cast<char *>(ctx->wf_pool) + (size_t)which * kEntryBytes * n;
     PathQ q;
-    q.ray_o = base; q.ray_d = base + ctx->wf_pool_entries; q.thr = base + 2 * ctx->wf_pool_entries;
-    q.rad = base + 3 * ctx->wf_pool_entries; q.rng = base + 4 * ctx->wf_pool_entries; q.hit = base + 5 * ctx->wf_pool_entries;
+    q.ray_o = reinterpret_cast<float4 *>(base); q.ray_d = q.ray_o + n; q.thr = q.ray_d + n; q.hit = q.thr + n;
+    q.rng = reinterpret_cast<float2 *>(q.hit + n);
     return q;
+}
+
+// (m, k) with floor(n / d) == (n * m) >> k for all n < 2^26 (Granlund & Montgomery): k = 26 + ceil(log2 d).
+void magic_div(uint32_t d, uint32_t *m, uint32_t *k) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    *k = 26 + l;
+    *m = (uint32_t)(((1ull << *k) / d) + 1);
 }
 
 // The streaming pipeline of rt_wavefront.h for one rt_render call.  Samples are rendered in
@@ -124,7 +136,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     size_t pool = need_samples < pool_want ? (need_samples + shard_q - 1) / shard_q * shard_q : pool_want;
     if (ctx->wf_pool_entries < pool) {
         if (ctx->wf_pool) { (void)hipStreamSynchronize(stream); (void)hipFree(ctx->wf_pool); ctx->wf_pool = nullptr; ctx->wf_pool_entries = 0; }
-        HIP_TRY(ctx, hipMalloc(&ctx->wf_pool, pool * 2 * 6 * 16));
+        HIP_TRY(ctx, hipMalloc(&ctx->wf_pool, pool * 2 * kEntryBytes));
         ctx->wf_pool_entries = pool;
     }
     if (!ctx->wf_ctr) {
@@ -135,9 +147,9 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     uint32_t *d_status = reinterpret_cast<uint32_t *>(ctx->wf_ctr + RT_WF_RING);
     const PathQ Q[2] = {pool_buffer(ctx, 0), pool_buffer(ctx, 1)};
     const bool has_bvh = ctx->sc.root_ref != RT_BVH_EMPTY;
-    const size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(uint2);
-    if (lds > 160 * 1024) return fail(ctx, RT_E_INVALID, "LDS budget exceeded (%zu bytes)", lds);
-    if (lds > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute((const void *)wf_traverse_kernel<STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // traversal stack: the first lds_depth entries of every lane in LDS, the (rarely reached) rest in HBM
+    const uint32_t lds_depth = (uint32_t)env_size("RT_WF_LDS_DEPTH", 20, 1, 64) < ctx->stack_depth ? (uint32_t)env_size("RT_WF_LDS_DEPTH", 20, 1, 64) : ctx->stack_depth;
+    const size_t lds = (size_t)lds_depth * 256 * sizeof(StackEntry);
     int per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_traverse_kernel<STATS>, 256, lds));
     {   // the runtime's answer may assume the 64 KB per-workgroup LDS limit; gfx950 has 160 KB per CU
@@ -153,16 +165,25 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     }
     if (per_cu < 1) per_cu = 1;
     const unsigned trav_blocks = ((unsigned)(per_cu * ctx->prop.multiProcessorCount) + RT_WF_SHARDS - 1) / RT_WF_SHARDS * RT_WF_SHARDS;
-    unsigned long long *d_stats = STATS ? ctx->d_stats : nullptr;
-    if (STATS) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 32 * sizeof(unsigned long long), stream));
+    const size_t ovf_entries = (size_t)(ctx->stack_depth - lds_depth) * trav_blocks * 256;
+    if (ovf_entries > ctx->wf_ovf_entries) {
+        if (ctx->wf_ovf) { (void)hipStreamSynchronize(stream); (void)hipFree(ctx->wf_ovf); ctx->wf_ovf = nullptr; ctx->wf_ovf_entries = 0; }
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->wf_ovf, ovf_entries * sizeof(StackEntry)));
+        ctx->wf_ovf_entries = ovf_entries;
+    }
+    StackEntry *d_ovf = ovf_entries ? ctx->wf_ovf : nullptr;
+    unsigned long long *d_stats = (STATS || kTimers) ? ctx->d_stats : nullptr;
+    if (STATS || kTimers) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 64 * sizeof(unsigned long long), stream));
 
     WfArgs w{};
     w.a = a;
     w.tiles_x = tiles_x; w.n_tiles = n_tiles;
+    magic_div(tiles_x, &w.tx_m, &w.tx_k);
     for (int32_t s0 = 0; s0 < a.spp_count; s0 += (int32_t)spp_batch_max) {
         w.spp_batch = (uint32_t)((size_t)(a.spp_count - s0) < spp_batch_max ? (size_t)(a.spp_count - s0) : spp_batch_max);
         w.sample0 = (uint32_t)(a.spp_begin + s0);
         w.n_items = (uint32_t)(per_sample * w.spp_batch);
+        magic_div(w.spp_batch, &w.spp_m, &w.spp_k);
         const size_t items_up = ((size_t)w.n_items + shard_q - 1) / shard_q * shard_q;
         w.pool = (uint32_t)(items_up < ctx->wf_pool_entries ? items_up : ctx->wf_pool_entries);
         if (w.pool > pool_want) w.pool = (uint32_t)pool_want;
@@ -185,7 +206,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             for (int k = 0; k < 8; ++k) {
                 ++it;
                 const PathQ &cur = Q[it & 1], &nxt = Q[(it + 1) & 1];
-                if (has_bvh) hipLaunchKernelGGL(wf_traverse_kernel<STATS>, dim3(trav_blocks), dim3(256), lds, stream, ctx->sc, cur, ctx->wf_ctr, it, w.cap, d_stats);
+                if (has_bvh) hipLaunchKernelGGL(wf_traverse_kernel<STATS>, dim3(trav_blocks), dim3(256), lds, stream, ctx->sc, cur, ctx->wf_ctr, it, w.cap, lds_depth, d_ovf, d_stats);
                 hipLaunchKernelGGL(wf_shade_kernel<STATS>, dim3(pool_blocks), dim3(256), 0, stream, ctx->sc, w, cur, nxt, ctx->wf_ctr, it,
                                    ctx->wf_samples, d_stats, d_rays);
                 hipLaunchKernelGGL(wf_generate_kernel<STATS>, dim3(pool_blocks), dim3(256), 0, stream, ctx->sc, w, nxt, ctx->wf_ctr, it,
@@ -197,6 +218,14 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         }
         hipLaunchKernelGGL(wf_fold_kernel, dim3((n_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, w, ctx->wf_samples, d_out);
         HIP_TRY(ctx, hipGetLastError());
+    }
+    if (kTimers && !STATS) {   // development build: print where the waves' cycles went
+        unsigned long long h[64];
+        HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        fprintf(stderr, "[rt-regions]");
+        for (int i = 0; i < RT_N_REGIONS; ++i) fprintf(stderr, " %llu", h[32 + i]);
+        fprintf(stderr, "\n");
     }
     return RT_OK;
 }
@@ -223,7 +252,7 @@ int rt_create(int device_id, rt_ctx **out) {
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_stats, 32 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_stats, 64 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         int st = fail(nullptr, RT_E_HIP, "rt_create: %s", hipGetErrorString(e));
         delete ctx;
@@ -243,6 +272,7 @@ void rt_destroy(rt_ctx *ctx) {
     if (ctx->wf_pool) (void)hipFree(ctx->wf_pool);
     if (ctx->wf_samples) (void)hipFree(ctx->wf_samples);
     if (ctx->wf_ctr) (void)hipFree(ctx->wf_ctr);
+    if (ctx->wf_ovf) (void)hipFree(ctx->wf_ovf);
     if (ctx->wf_host_status) (void)hipHostFree(ctx->wf_host_status);
     for (hipEvent_t ev : ctx->wf_event) if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -323,7 +353,19 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     auto &own = ctx->scene_allocs;
 #define UP(field, src, bytes) if ((st = upload(ctx, own, src, bytes, &d.field)) != RT_OK) return st
     UP(nodes, s->bvh_nodes, (size_t)s->n_bvh_nodes * RT_NODE_FLOATS * 4);
-    UP(slots, s->slots, (size_t)s->n_slots * RT_SLOT_FLOATS * 4);
+    {   // device copy of the slots: spheres and rectangles under a transform get that transform's record in
+        // words 8..15 (rt_kernels.h SlotRec), so a hit test is one 64-byte fetch
+        std::vector<float> dev_slots(s->slots, s->slots + (size_t)s->n_slots * RT_SLOT_FLOATS);
+        for (uint32_t i = 0; i < s->n_slots; ++i) {
+            int32_t w4;
+            memcpy(&w4, &dev_slots[(size_t)i * RT_SLOT_FLOATS + 4], 4);
+            int type = w4 & 15, xf = (w4 >> 8) - 1;
+            if (xf >= 0 && type != RT_PRIM_MOVING_SPHERE && type != RT_PRIM_TRIANGLE)
+                memcpy(&dev_slots[(size_t)i * RT_SLOT_FLOATS + 8], &s->xforms[(size_t)xf * RT_REC_FLOATS], RT_REC_FLOATS * 4);
+        }
+        UP(slots, dev_slots.data(), dev_slots.size() * 4);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // dev_slots goes out of scope
+    }
     UP(attrs, s->tri_attrs, tris ? (size_t)s->n_slots * RT_ATTR_FLOATS * 4 : 0);
     UP(xforms, s->xforms, (size_t)s->n_xforms * RT_REC_FLOATS * 4);
     UP(media, s->media, (size_t)s->n_media * RT_REC_FLOATS * 4);
@@ -441,7 +483,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
     int tile_w = 2 << ((rb + 1) >> 1), tile_h = 2 << (rb >> 1);
     int tiles_x = (x1 - x0 + tile_w - 1) / tile_w, tiles_y = (y1 - y0 + tile_h - 1) / tile_h;
     dim3 grid((unsigned)(tiles_x * tiles_y)), block(256);
-    size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(uint2) + (size_t)4 * 3 * sizeof(float) * ((size_t)chunk << rb);
+    size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(StackEntry) + (size_t)4 * 3 * sizeof(float) * ((size_t)chunk << rb);
     if (lds > 160 * 1024) return fail(ctx, RT_E_INVALID, "LDS budget exceeded (%zu bytes)", lds);
     hipError_t e = hipSuccess;
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit the kernel has to be told
@@ -452,13 +494,13 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
     if (wavefront) {
         // already enqueued above
     } else if (p->collect_stats) {
-        e = hipMemsetAsync(ctx->d_stats, 0, 32 * sizeof(unsigned long long), stream);
+        e = hipMemsetAsync(ctx->d_stats, 0, 64 * sizeof(unsigned long long), stream);
         if (e == hipSuccess) hipLaunchKernelGGL(render_kernel<true>, grid, block, lds, stream, ctx->sc, a, d_out, ctx->d_stats, d_rays);
     } else {
         hipLaunchKernelGGL(render_kernel<false>, grid, block, lds, stream, ctx->sc, a, d_out, (unsigned long long *)nullptr, (uint32_t *)nullptr);
     }
     if (e == hipSuccess) e = hipGetLastError();
-    unsigned long long h_stats[32] = {};
+    unsigned long long h_stats[64] = {};
     if (e == hipSuccess && p->collect_stats) {
         e = hipMemcpyAsync(h_stats, ctx->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -481,6 +523,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
         for (int i = 0; i < 4; ++i) stats->tex_evals[i] = h_stats[16 + i];
         stats->accepted_hits = h_stats[20];
         for (int i = 0; i < 5; ++i) { stats->phase_lanes[i] = h_stats[21 + i]; stats->phase_slots[i] = h_stats[26 + i]; }
+        for (int i = 0; i < RT_N_REGIONS; ++i) stats->region_cycles[i] = h_stats[32 + i];
     }
     return RT_OK;
 }
@@ -533,7 +576,7 @@ int rt_trace_first_hit(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_mi
     hipError_t e = hipMemcpyAsync(d, rays_soa, 28 * N, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) {
         dim3 grid((unsigned)((N + 255) / 256)), block(256);
-        size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(uint2);
+        size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(StackEntry);
         hipLaunchKernelGGL(first_hit_kernel, grid, block, lds, stream, ctx->sc, (const float *)d, n, t_min, t_max,
                            (uint32_t *)(d + off_prim), (float *)(d + off_t), (float *)(d + off_n), (uint8_t *)(d + off_ff),
                            (float *)(d + off_uv));

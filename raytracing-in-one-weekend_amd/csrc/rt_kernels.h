@@ -103,10 +103,30 @@ struct DScene {
     uint32_t n_slots, always_begin, always_count, n_media, n_lights, n_moving, n_rects, sets, spp;
 };
 
+#define RT_N_REGIONS 24
 struct Counters {  // only live in the STATS instantiation
     uint32_t rays, node_visits, prim_tests[6], medium_tests, light_pdf_evals, shades[5], tex_evals[4], accepted;
     uint32_t phase_lanes[5], phase_slots[5];
+    uint32_t region[RT_N_REGIONS];   // cycles a wave spent in a code region (counted on its first active lane)
 };
+// Region timers (development builds with -DRT_REGION_TIMERS=1 only; they time the product kernels, not the
+// counting variant, whose counters distort it): RG_BEGIN/RG_END bracket a piece of code, also inside
+// divergent control flow — the scalar cycle counter is read once per wave execution of the region.
+#ifndef RT_REGION_TIMERS
+#define RT_REGION_TIMERS 0
+#endif
+constexpr bool kTimers = RT_REGION_TIMERS != 0;
+enum { RG_LOAD = 0, RG_FINISH, RG_RECORD, RG_TEXTURE, RG_EMIT, RG_METAL, RG_DIEL, RG_ISO, RG_LAMBERT, RG_L_LIGHTS, RG_L_COSINE,
+       RG_L_PDF, RG_B_MEDIA, RG_B_RECTS, RG_B_ALWAYS, RG_B_REST, RG_STORE, RG_NODE, RG_LEAF, RG_FETCH, RG_CAMERA, RG_SHADE_ALL, RG_BEGIN_ALL };
+#define RG_BEGIN(k) unsigned long long rg_t_##k = (kTimers && !STATS) ? __builtin_readcyclecounter() : 0ull
+#define RG_END(k)                                                                                              \
+    do {                                                                                                       \
+        if (kTimers && !STATS) {                                                                               \
+            const unsigned long long rg_m = __ballot(1);                                                       \
+            if ((rg_m & (0ull - rg_m)) == (1ull << (threadIdx.x & 63u)))                                       \
+                cnt.region[k] += (uint32_t)(__builtin_readcyclecounter() - rg_t_##k);                          \
+        }                                                                                                      \
+    } while (0)
 enum { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_START = 3, PH_BEGIN = 4 };
 
 struct Hit {      // what the search tracks
@@ -125,8 +145,7 @@ struct Rec {      // HitRecord (hittable.rs:6-14)
 /* ------------------------------------------------------------------ primitive tests */
 
 // Ray into the frame of a wrapped primitive: Translate (transform.rs:34) then RotateY (:117-126).
-RT_DEV Ray to_object(const DScene &sc, int xf, const Ray &r) {
-    float4 a = sc.xforms[2 * xf], b = sc.xforms[2 * xf + 1];
+RT_DEV Ray to_object_rec(float4 a, float4 b, const Ray &r) {
     int flags = f2i(a.x);
     float sin_t = a.y, cos_t = a.z;
     Ray q = r;
@@ -140,6 +159,22 @@ RT_DEV Ray to_object(const DScene &sc, int xf, const Ray &r) {
     }
     return q;
 }
+RT_DEV Ray to_object(const DScene &sc, int xf, const Ray &r) { return to_object_rec(sc.xforms[2 * xf], sc.xforms[2 * xf + 1], r); }
+
+// A slot as the kernels read it: all 64 bytes at once, so that the loads of a test do not wait on
+// each other.  In the DEVICE copy of the slot array, spheres and rectangles under a transform carry
+// that transform's record in words 8..15 (unused by those types; written by rt_scene_upload), so
+// their test needs no second, dependent load; moving spheres and triangles go through sc.xforms.
+struct SlotRec {
+    float4 q0, meta, q2, q3;
+};
+RT_DEV SlotRec load_slot(const DScene &sc, uint32_t slot) {
+    const float4 *p = sc.slots + 4 * (size_t)slot;
+    SlotRec s;
+    s.q0 = p[0]; s.meta = p[1]; s.q2 = p[2]; s.q3 = p[3];
+    return s;
+}
+RT_DEV bool type_has_inline_xform(int type) { return type != RT_PRIM_MOVING_SPHERE && type != RT_PRIM_TRIANGLE; }
 
 RT_DEV bool sphere_roots(V3 center, float radius, const Ray &r, float t_min, float t_max, float *t_out) {  // sphere.rs:45-66
     V3 oc = r.o - center;
@@ -211,32 +246,37 @@ RT_DEV bool tri_test(const DScene &sc, uint32_t slot, float4 q0, float p3z, floa
 
 // Hit test of one slot: true + t when `obj.hit(r, t_min, t_max)` of that leaf would return Some.
 template <bool STATS>
-RT_DEV bool slot_hit(const DScene &sc, uint32_t slot, const Ray &r_world, float t_min, float t_max, float *t_out, int32_t *id_out,
-                     Counters &cnt) {
-    float4 q0 = sc.slots[4 * (size_t)slot], meta = sc.slots[4 * (size_t)slot + 1];
+RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, const Ray &r_world, float t_min, float t_max, float *t_out,
+                         int32_t *id_out, Counters &cnt) {
+    const float4 q0 = s.q0, meta = s.meta;
     int w4 = f2i(meta.x);
     int type = w4 & 15;
     int xf = (w4 >> 8) - 1;
     *id_out = f2i(meta.z);
     if (STATS) cnt.prim_tests[type] += 1;
-    Ray r = xf >= 0 ? to_object(sc, xf, r_world) : r_world;
+    Ray r = r_world;
+    if (xf >= 0) r = type_has_inline_xform(type) ? to_object_rec(s.q2, s.q3, r_world) : to_object(sc, xf, r_world);
     float a, b;
     switch (type) {
     case RT_PRIM_SPHERE: case RT_PRIM_MOVING_SPHERE: {   // one sphere_roots for both kinds: only the centre differs
         V3 c = v3(q0.x, q0.y, q0.z);
-        if (type == RT_PRIM_MOVING_SPHERE) c = moving_center(q0, meta.w, sc.slots[4 * (size_t)slot + 2], r.time);
+        if (type == RT_PRIM_MOVING_SPHERE) c = moving_center(q0, meta.w, s.q2, r.time);
         return sphere_roots(c, q0.w, r, t_min, t_max, t_out);
     }
     case RT_PRIM_XY_RECT: case RT_PRIM_XZ_RECT: case RT_PRIM_YZ_RECT:
         return rect_test(type, q0, meta.w, r, t_min, t_max, t_out, &a, &b);
     default: {
-        float4 q2 = sc.slots[4 * (size_t)slot + 2];
         TriHit th;
-        if (!tri_test(sc, slot, q0, meta.w, q2, r, t_min, t_max, &th)) return false;
+        if (!tri_test(sc, slot, q0, meta.w, s.q2, r, t_min, t_max, &th)) return false;
         *t_out = th.t;
         return true;
     }
     }
+}
+template <bool STATS>
+RT_DEV bool slot_hit(const DScene &sc, uint32_t slot, const Ray &r_world, float t_min, float t_max, float *t_out, int32_t *id_out,
+                     Counters &cnt) {
+    return slot_hit_rec<STATS>(sc, slot, load_slot(sc, slot), r_world, t_min, t_max, t_out, id_out, cnt);
 }
 
 RT_DEV void sphere_uv(V3 p, float *u, float *v) {  // sphere.rs:25-41
@@ -249,11 +289,17 @@ RT_DEV void sphere_uv(V3 p, float *u, float *v) {  // sphere.rs:25-41
 // Full HitRecord of a slot for a known t: the same arithmetic as the leaf's hit() followed by
 // the wrappers on the way out (RotateY transform.rs:128-143, Translate :35-44, FlipFace).
 RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, float t, bool want_uv) {
-    float4 q0 = sc.slots[4 * (size_t)slot], meta = sc.slots[4 * (size_t)slot + 1];
+    const SlotRec s = load_slot(sc, slot);
+    float4 q0 = s.q0, meta = s.meta;
     int w4 = f2i(meta.x);
     int type = w4 & 15;
     int xf = (w4 >> 8) - 1;
-    Ray r = xf >= 0 ? to_object(sc, xf, r_world) : r_world;
+    float4 xa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), xb = xa;
+    if (xf >= 0) {
+        if (type_has_inline_xform(type)) { xa = s.q2; xb = s.q3; }
+        else { xa = sc.xforms[2 * xf]; xb = sc.xforms[2 * xf + 1]; }
+    }
+    Ray r = xf >= 0 ? to_object_rec(xa, xb, r_world) : r_world;
     Rec rec;
     rec.t = t;
     rec.material = f2i(meta.y);
@@ -262,7 +308,7 @@ RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, floa
     switch (type) {
     case RT_PRIM_SPHERE: case RT_PRIM_MOVING_SPHERE: {
         V3 c = v3(q0.x, q0.y, q0.z);
-        if (type == RT_PRIM_MOVING_SPHERE) c = moving_center(q0, meta.w, sc.slots[4 * (size_t)slot + 2], r.time);
+        if (type == RT_PRIM_MOVING_SPHERE) c = moving_center(q0, meta.w, s.q2, r.time);
         n = (p - c) / q0.w;
         if (want_uv) sphere_uv(n, &rec.u, &rec.v);
         break;
@@ -279,9 +325,8 @@ RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, floa
         break;
     }
     default: {
-        float4 q2 = sc.slots[4 * (size_t)slot + 2];
         TriHit th;
-        tri_test(sc, slot, q0, meta.w, q2, r, -RT_F32_MAX, RT_F32_MAX, &th);  // same arithmetic as the accepted test
+        tri_test(sc, slot, q0, meta.w, s.q2, r, -RT_F32_MAX, RT_F32_MAX, &th);  // same arithmetic as the accepted test
         n = th.n;
         float4 a2 = sc.attrs[4 * (size_t)slot + 2], a3 = sc.attrs[4 * (size_t)slot + 3];
         rec.u = th.b0 * a2.y + th.b1 * a2.w + th.b2 * a3.y;
@@ -292,7 +337,6 @@ RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, floa
     bool front = dot(r.d, n) < 0.0f;  // hittable.rs:26
     V3 nn = front ? n : -n;
     if (xf >= 0) {
-        float4 xa = sc.xforms[2 * xf], xb = sc.xforms[2 * xf + 1];
         int flags = f2i(xa.x);
         if (flags & 1) {
             float sin_t = xa.y, cos_t = xa.z;
@@ -335,20 +379,32 @@ RT_DEV bool slab(V3 lo, V3 hi, V3 inv, V3 oi, float t_min, float t_max, float *t
 }
 
 // Next stack entry whose box can still hold a closer-or-equal hit, or RT_BVH_EMPTY.
-RT_DEV int32_t pop_ref(const uint2 *stack, uint32_t stride, uint32_t &sp, float best_t) {
-    while (sp != 0) {
-        --sp;
-        uint2 e = stack[sp * stride];
-        if (__uint_as_float(e.y) <= best_t) return (int32_t)e.x;
-    }
-    return RT_BVH_EMPTY;
+// Traversal stack of one lane: 4-byte node refs, the first lds_depth entries in LDS (column `lane` of a
+// [depth][block] array, so a wave's accesses hit 64 different banks), deeper ones in an HBM overflow area.
+// Entries carry no entry distance: LDS bytes per wave decide how many waves a CU holds, and the walk is
+// latency-bound; a stale entry costs one node visit (both child boxes then fail against best.t).
+typedef uint32_t StackEntry;
+struct Stack {
+    StackEntry *lds;  uint32_t stride;
+    uint32_t lds_depth;
+    StackEntry *ovf;  uint32_t ovf_stride;   // unused (null) when lds_depth covers the BVH depth
+};
+RT_DEV void stack_push(const Stack &st, uint32_t &sp, int32_t ref) {
+    if (sp < st.lds_depth) st.lds[sp * st.stride] = (uint32_t)ref;
+    else st.ovf[(size_t)(sp - st.lds_depth) * st.ovf_stride] = (uint32_t)ref;
+    ++sp;
+}
+RT_DEV int32_t pop_ref(const Stack &st, uint32_t &sp) {
+    if (sp == 0) return RT_BVH_EMPTY;
+    --sp;
+    return (int32_t)(sp < st.lds_depth ? st.lds[sp * st.stride] : st.ovf[(size_t)(sp - st.lds_depth) * st.ovf_stride]);
 }
 
 // "while-while" traversal: every lane walks inner nodes until it stands on a leaf (or is done);
 // only then does the wave run the primitive tests, so node steps and leaf steps are not
 // serialised against each other inside one iteration.
 template <bool STATS>
-RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_id, Hit &best, uint2 *stack, uint32_t stride, Counters &cnt) {
+RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_id, Hit &best, const Stack &stack, Counters &cnt) {
     int32_t ref = sc.root_ref;
     if (ref == RT_BVH_EMPTY) return;
     // For the box tests only, a direction component below 1e-30 in magnitude is replaced by 1e-30:
@@ -370,15 +426,14 @@ RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_
             int32_t rl = f2i(d.x), rr = f2i(d.y);
             if (hl && hr) {
                 bool left_first = tl <= tr;
-                stack[sp * stride] = make_uint2((uint32_t)(left_first ? rr : rl), __float_as_uint(left_first ? tr : tl));
-                ++sp;
+                stack_push(stack, sp, left_first ? rr : rl);
                 ref = left_first ? rl : rr;
             } else if (hl) {
                 ref = rl;
             } else if (hr) {
                 ref = rr;
             } else {
-                ref = pop_ref(stack, stride, sp, best.t);
+                ref = pop_ref(stack, sp);
             }
         }
         if (ref == RT_BVH_EMPTY) return;
@@ -389,7 +444,7 @@ RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_
             int32_t id;
             if (slot_hit<STATS>(sc, first + i, r, t_min, best.t, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)(first + i));
         }
-        ref = pop_ref(stack, stride, sp, best.t);
+        ref = pop_ref(stack, sp);
     }
 }
 
@@ -471,7 +526,7 @@ RT_DEV void closest_hit_exhaustive(const DScene &sc, const Ray &r, float t_min, 
 // numbers), everything folded with list semantics.  `with_media` = false for the parity hook.
 template <bool STATS>
 RT_DEV bool closest_hit(const DScene &sc, const Ray &r, float t_min, float t_max, bool with_media, rts::Rng &rng, Hit &best,
-                        uint2 *stack, uint32_t stride, Counters &cnt) {
+                        const Stack &stack, Counters &cnt) {
     float med_t[RT_MAX_MEDIA];
     bool med_ok[RT_MAX_MEDIA];
 #pragma unroll
@@ -504,7 +559,7 @@ RT_DEV bool closest_hit(const DScene &sc, const Ray &r, float t_min, float t_max
         uint32_t s = sc.always_begin + i;
         if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)s);
     }
-    traverse<STATS>(sc, r, t_min, floor_id, best, stack, stride, cnt);
+    traverse<STATS>(sc, r, t_min, floor_id, best, stack, cnt);
     // MovingSphere boxes cover the shutter interval only; isotropic.rs:32 can hand a ray any "time"
     if (sc.n_moving && !(r.time >= 0.0f && r.time <= 1.0f))
         for (uint32_t i = 0; i < sc.n_moving; ++i) {
@@ -539,11 +594,13 @@ template <bool STATS>
 RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max, rts::Rng &rng, Trav &tv, Counters &cnt) {
     float med_t[RT_MAX_MEDIA];
     bool med_ok[RT_MAX_MEDIA];
+    RG_BEGIN(RG_B_MEDIA);
 #pragma unroll
     for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m) {
         med_ok[m] = false; med_t[m] = 0.0f;
         if (m < sc.n_media) med_ok[m] = medium_hit<STATS>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
     }
+    RG_END(RG_B_MEDIA);
     tv.floor_id = -1; tv.sp = 0; tv.ref = RT_BVH_EMPTY;
     if (!ray_is_finite(r)) {
         closest_hit_exhaustive<STATS>(sc, r, t_min, t_max, med_t, med_ok, tv.best, cnt);
@@ -555,11 +612,18 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
             if (slot_hit<STATS>(sc, sc.rects[i], r, t_min, t_max, &t, &id, cnt) && t != t && id > tv.floor_id) tv.floor_id = id;
         }
     tv.best.t = t_max; tv.best.id = -1; tv.best.slot = 0;
-    for (uint32_t i = 0; i < sc.always_count; ++i) {
-        float t; int32_t id;
-        uint32_t s = sc.always_begin + i;
-        if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)s);
+    RG_BEGIN(RG_B_ALWAYS);
+    if (sc.always_count) {   // the slot index is wave-uniform: fetch slot i+1 while slot i is tested
+        SlotRec nx = load_slot(sc, sc.always_begin);
+        for (uint32_t i = 0; i < sc.always_count; ++i) {
+            const SlotRec cu = nx;
+            const uint32_t s = sc.always_begin + i;
+            if (i + 1 < sc.always_count) nx = load_slot(sc, s + 1);
+            float t; int32_t id;
+            if (slot_hit_rec<STATS>(sc, s, cu, r, t_min, t_max, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)s);
+        }
     }
+    RG_END(RG_B_ALWAYS);
     if (sc.n_moving && !(r.time >= 0.0f && r.time <= 1.0f))
         for (uint32_t i = 0; i < sc.n_moving; ++i) {
             float t; int32_t id;
@@ -580,7 +644,7 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
 }
 
 template <bool STATS>
-RT_DEV void trav_node_step(const DScene &sc, float t_min, Trav &tv, uint2 *stack, uint32_t stride, Counters &cnt) {
+RT_DEV void trav_node_step(const DScene &sc, float t_min, Trav &tv, const Stack &stack, Counters &cnt) {
     const float4 *n = sc.nodes + 4 * (size_t)tv.ref;
     float4 a = n[0], b = n[1], c = n[2], d = n[3];
     if (STATS) cnt.node_visits += 1;
@@ -590,20 +654,19 @@ RT_DEV void trav_node_step(const DScene &sc, float t_min, Trav &tv, uint2 *stack
     int32_t rl = f2i(d.x), rr = f2i(d.y);
     if (hl && hr) {
         bool left_first = tl <= tr;
-        stack[tv.sp * stride] = make_uint2((uint32_t)(left_first ? rr : rl), __float_as_uint(left_first ? tr : tl));
-        ++tv.sp;
+        stack_push(stack, tv.sp, left_first ? rr : rl);
         tv.ref = left_first ? rl : rr;
     } else if (hl) {
         tv.ref = rl;
     } else if (hr) {
         tv.ref = rr;
     } else {
-        tv.ref = pop_ref(stack, stride, tv.sp, tv.best.t);
+        tv.ref = pop_ref(stack, tv.sp);
     }
 }
 
 template <bool STATS>
-RT_DEV void trav_leaf_step(const DScene &sc, const Ray &r, float t_min, Trav &tv, const uint2 *stack, uint32_t stride, Counters &cnt) {
+RT_DEV void trav_leaf_step(const DScene &sc, const Ray &r, float t_min, Trav &tv, const Stack &stack, Counters &cnt) {
     uint32_t code = (uint32_t)~tv.ref;
     uint32_t first = code >> 3, count = (code & 7u) + 1u;
     for (uint32_t i = 0; i < count; ++i) {
@@ -611,7 +674,7 @@ RT_DEV void trav_leaf_step(const DScene &sc, const Ray &r, float t_min, Trav &tv
         int32_t id;
         if (slot_hit<STATS>(sc, first + i, r, t_min, tv.best.t, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)(first + i));
     }
-    tv.ref = pop_ref(stack, stride, tv.sp, tv.best.t);
+    tv.ref = pop_ref(stack, tv.sp);
 }
 
 // After the walk: if nothing came after the last NaN candidate, that candidate is the hit.
@@ -863,7 +926,9 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
         int mtype = f2i(ma.x);
         bool want_uv = (mtype == RTG_MAT_LAMBERTIAN || mtype == RTG_MAT_DIFFUSE_LIGHT || mtype == RTG_MAT_ISOTROPIC) &&
                        texture_needs_uv(sc, f2i(ma.y));
+        RG_BEGIN(RG_RECORD);
         rec = slot_record(sc, (uint32_t)best.slot, ps.ray, best.t, want_uv);
+        RG_END(RG_RECORD);
     }
     float4 ma = sc.materials[2 * rec.material], mb = sc.materials[2 * rec.material + 1];
     int mtype = f2i(ma.x);
@@ -871,21 +936,26 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
     const Ray &r = ps.ray;
     switch (mtype) {
     case RTG_MAT_DIFFUSE_LIGHT: {  // diffuse_light.rs:43-56; scatter = None -> return emitted
+        RG_BEGIN(RG_EMIT);
         if (rec.front_face) {
             V3 e = texture_value<STATS>(sc, f2i(ma.y), rec.u, rec.v, rec.p, cnt);
             ps.radiance = ps.radiance + ps.throughput * e;
         }
+        RG_END(RG_EMIT);
         return false;
     }
     case RTG_MAT_METAL: {  // metal.rs:21-36
+        RG_BEGIN(RG_METAL);
         V3 reflected = reflect_unit_vector(r.d, normalize(rec.normal));
         V3 scattered = reflected + mb.y * random_in_unit_sphere(rng);
+        RG_END(RG_METAL);
         if (!(dot(scattered, rec.normal) > 0.0f)) return false;  // None -> emitted = 0
         ps.throughput = ps.throughput * v3(ma.z, ma.w, mb.x);
         ps.ray = Ray{rec.p, scattered, r.time};
         break;
     }
     case RTG_MAT_DIELECTRIC: {  // dielectric.rs:17-67
+        RG_BEGIN(RG_DIEL);
         float ior = mb.z;
         float eta = rec.front_face ? 1.0f / ior : ior;
         V3 uv = normalize(r.d);
@@ -901,23 +971,38 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
         }
         ps.throughput = ps.throughput * v3(1.0f, 1.0f, 1.0f);
         ps.ray = Ray{rec.p, dir, r.time};
+        RG_END(RG_DIEL);
         break;
     }
     case RTG_MAT_ISOTROPIC: {  // isotropic.rs:26-35
+        RG_BEGIN(RG_ISO);
         V3 dir = random_in_unit_sphere(rng);
         V3 att = texture_value<STATS>(sc, f2i(ma.y), rec.u, rec.v, rec.p, cnt);
         ps.throughput = ps.throughput * att;
         ps.ray = Ray{rec.p, dir, rec.t};  // sic: time = hit t
+        RG_END(RG_ISO);
         break;
     }
     default: {  // Lambertian: lambertian.rs:33-51 + camera.rs:271-301
+        RG_BEGIN(RG_LAMBERT);
+        RG_BEGIN(RG_TEXTURE);
         V3 albedo = texture_value<STATS>(sc, f2i(ma.y), rec.u, rec.v, rec.p, cnt);
+        RG_END(RG_TEXTURE);
         Onb uvw = onb_from(rec.normal);
         V3 dir;
-        if (rts::random_real(rng) < 0.5f) dir = lights_random(sc, rec.p, rng);
-        else dir = onb_local(uvw, random_cosine_direction(rng));
+        if (rts::random_real(rng) < 0.5f) {
+            RG_BEGIN(RG_L_LIGHTS);
+            dir = lights_random(sc, rec.p, rng);
+            RG_END(RG_L_LIGHTS);
+        } else {
+            RG_BEGIN(RG_L_COSINE);
+            dir = onb_local(uvw, random_cosine_direction(rng));
+            RG_END(RG_L_COSINE);
+        }
         // MixturePdf::value (pdf.rs:68-70)
+        RG_BEGIN(RG_L_PDF);
         float light_val = lights_pdf_value<STATS>(sc, rec.p, dir, cnt);
+        RG_END(RG_L_PDF);
         float cosine = dot(normalize(dir), uvw.w);
         float cos_val = cosine <= 0.0f ? 0.0f : cosine * (float)0.318309886183790671537767526745028724;
         float pdf_val = 0.5f * light_val + 0.5f * cos_val;
@@ -926,6 +1011,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
         float spdf = sc_cos < 0.0f ? 0.0f : sc_cos / 3.14159265358979323846f;
         ps.throughput = ps.throughput * ((albedo * spdf) / pdf_val);
         ps.ray = Ray{rec.p, dir, r.time};
+        RG_END(RG_LAMBERT);
         break;
     }
     }
@@ -1000,7 +1086,7 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 template <bool STATS>
 __global__ void __launch_bounds__(256) render_kernel(DScene sc, RenderArgs a, float4 *__restrict__ out, unsigned long long *stats,
                                                      uint32_t *pixel_rays) {
-    extern __shared__ uint2 lds_stack[];
+    extern __shared__ StackEntry lds_stack[];
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     const uint32_t rb = 6u - (uint32_t)a.sub_log2;          // log2(P)
@@ -1011,8 +1097,7 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, RenderArgs a, fl
     const int bx = (int)(blockIdx.x % (uint32_t)tiles_x), by = (int)(blockIdx.x / (uint32_t)tiles_x);
     const int wave_x0 = a.x0 + bx * tile_w + (int)((wave & 1u) << wx_log);
     const int wave_y0 = a.y0 + by * tile_h + (int)((wave >> 1) << wy_log);
-    uint2 *stack = lds_stack + tid;
-    const uint32_t stride = blockDim.x;
+    const Stack stack{lds_stack + tid, blockDim.x, (uint32_t)a.stack_depth, nullptr, 0u};
     const uint32_t slots = P * (uint32_t)a.chunk;            // radiance slots of this wave
     float *rad = reinterpret_cast<float *>(lds_stack + (size_t)a.stack_depth * 256u) + (size_t)wave * 3u * slots;
     Counters cnt{};
@@ -1047,13 +1132,13 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, RenderArgs a, fl
                 int nt = n_trav;
                 do {
                     phase_count<STATS>(cnt, PH_NODE, st == ST_TRAV && tv.ref >= 0);
-                    if (st == ST_TRAV && tv.ref >= 0) trav_node_step<STATS>(sc, T_MIN, tv, stack, stride, cnt);
+                    if (st == ST_TRAV && tv.ref >= 0) trav_node_step<STATS>(sc, T_MIN, tv, stack, cnt);
                     const bool at_leaf = st == ST_TRAV && tv.ref < 0;
                     const unsigned long long m_leaf = __ballot(at_leaf);
                     const unsigned long long m_node = __ballot(st == ST_TRAV && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
                     if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
                         phase_count<STATS>(cnt, PH_LEAF, at_leaf);
-                        if (at_leaf) trav_leaf_step<STATS>(sc, ps.ray, T_MIN, tv, stack, stride, cnt);
+                        if (at_leaf) trav_leaf_step<STATS>(sc, ps.ray, T_MIN, tv, stack, cnt);
                     }
                     if (st == ST_TRAV && tv.ref == RT_BVH_EMPTY) {
                         finish_trace<STATS>(sc, ps.ray, T_MIN, T_MAX, tv, cnt);
@@ -1142,7 +1227,7 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, RenderArgs a, fl
 // Parity hook: world.hit without media for caller-supplied rays (rt_trace_first_hit).
 __global__ void __launch_bounds__(256) first_hit_kernel(DScene sc, const float *__restrict__ rays, int n, float t_min, float t_max,
                                                         uint32_t *prim_id, float *t_out, float *normal3, uint8_t *front_face, float *uv2) {
-    extern __shared__ uint2 lds_stack[];
+    extern __shared__ StackEntry lds_stack[];
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
     Ray r;
@@ -1152,7 +1237,8 @@ __global__ void __launch_bounds__(256) first_hit_kernel(DScene sc, const float *
     Counters cnt{};
     rts::Rng rng{0, 1};
     Hit best;
-    bool h = closest_hit<false>(sc, r, t_min, t_max, false, rng, best, lds_stack + threadIdx.x, blockDim.x, cnt);
+    const Stack stack{lds_stack + threadIdx.x, blockDim.x, 0xffffffffu, nullptr, 0u};   // launched with the full BVH depth in LDS
+    bool h = closest_hit<false>(sc, r, t_min, t_max, false, rng, best, stack, cnt);
     Rec rec{};
     if (h) rec = slot_record(sc, (uint32_t)best.slot, r, best.t, true);
     prim_id[i] = h ? (uint32_t)best.id : RT_MISS;

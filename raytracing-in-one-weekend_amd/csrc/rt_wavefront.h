@@ -17,8 +17,10 @@
 // iteration its pieces run in, so the image is the same bits as the per-lane megakernel's (and the
 // fold is the reference's order exactly, independent of pool size and launch geometry).
 //
-// Pool entry = 6 float4 in SoA arrays (96 B): origin+time | direction+flags | throughput+pixel |
-// radiance+sample | rng state+item | hit (t, id, slot, floor_id).  Two pool buffers (ping-pong).
+// Pool entry = 72 B in five SoA arrays: origin+time | direction+flags | throughput+item | rng state |
+// hit (t, id, slot, floor_id).  Two pool buffers (ping-pong).  A path in flight carries no radiance:
+// every reference material either scatters with emitted() = black (material.rs:24-26) or emits and
+// ends the path (diffuse_light.rs:36-41), so radiance is only ever added by the bounce that ends it.
 #ifndef RT_WAVEFRONT_H
 #define RT_WAVEFRONT_H
 
@@ -29,9 +31,8 @@ namespace rtk {
 struct PathQ {
     float4 *ray_o;   // o.x o.y o.z time
     float4 *ray_d;   // d.x d.y d.z flags (depth | WF_ALIVE | WF_WALK)
-    float4 *thr;     // throughput.xyz, pixel index
-    float4 *rad;     // radiance.xyz, absolute sample index
-    float4 *rng;     // PCG state lo, hi, item index, -
+    float4 *thr;     // throughput.xyz, item index
+    float2 *rng;     // PCG state lo, hi (the stream constant follows from pixel and sample)
     float4 *hit;     // best.t, best.id, best.slot, floor_id
 };
 
@@ -51,6 +52,7 @@ struct WfShard {
     uint32_t item_head;  // (shard 0 only) first item not handed out when this iteration's generate runs
     uint32_t pad[60];
 };
+static_assert(RT_WF_SHARDS == 64u, "generate sums the shard counters with one wave");
 struct WfCounters {      // one per iteration, in a ring; written by the previous iteration's generate
     WfShard sh[RT_WF_SHARDS];
 };
@@ -63,14 +65,18 @@ struct WfArgs {
     uint32_t spp_batch;   // samples per pixel in this batch
     uint32_t sample0;     // absolute index of the batch's first sample
     uint32_t tiles_x, n_tiles;   // 8x8 pixel tiles over the window
+    uint32_t spp_m, spp_k, tx_m, tx_k;   // n / spp_batch and n / tiles_x as (n * m) >> k, exact for n < 2^26
 };
+
+// floor(n / d) for n < 2^26 with (m, k) from the host's magic_div(): k = 26 + ceil(log2 d), m = floor(2^k / d) + 1.
+RT_DEV uint32_t div_magic(uint32_t n, uint32_t m, uint32_t k) { return (uint32_t)(((uint64_t)n * (uint64_t)m) >> k); }
 
 // item -> (pixel, sample): 64 consecutive items are one 8x8 tile at one sample; a tile's samples are
 // consecutive groups.  The sample buffer uses the same index, so the fold reads it coalesced.
 RT_DEV bool item_pixel(const WfArgs &w, uint32_t g, int *x, int *y, uint32_t *sample) {
     const uint32_t group = g >> 6, ln = g & 63u;
-    const uint32_t t = group / w.spp_batch, k = group - t * w.spp_batch;
-    const uint32_t ty = t / w.tiles_x, tx = t - ty * w.tiles_x;
+    const uint32_t t = div_magic(group, w.spp_m, w.spp_k), k = group - t * w.spp_batch;
+    const uint32_t ty = div_magic(t, w.tx_m, w.tx_k), tx = t - ty * w.tiles_x;
     *x = w.a.x0 + (int)(tx * 8u + (ln & 7u));
     *y = w.a.y0 + (int)(ty * 8u + (ln >> 3));
     *sample = w.sample0 + k;
@@ -87,10 +93,8 @@ RT_DEV void store_entry(const PathQ &q, uint32_t i, const WfPath &p, const Trav 
     const uint32_t flags = ((uint32_t)p.ps.depth & WF_DEPTH_MASK) | WF_ALIVE | (walk ? WF_WALK : 0u);
     q.ray_o[i] = make_float4(p.ps.ray.o.x, p.ps.ray.o.y, p.ps.ray.o.z, p.ps.ray.time);
     q.ray_d[i] = make_float4(p.ps.ray.d.x, p.ps.ray.d.y, p.ps.ray.d.z, __uint_as_float(flags));
-    q.thr[i] = make_float4(p.ps.throughput.x, p.ps.throughput.y, p.ps.throughput.z, __uint_as_float(p.pixel));
-    q.rad[i] = make_float4(p.ps.radiance.x, p.ps.radiance.y, p.ps.radiance.z, __uint_as_float(p.sample));
-    q.rng[i] = make_float4(__uint_as_float((uint32_t)p.rng.state), __uint_as_float((uint32_t)(p.rng.state >> 32)),
-                           __uint_as_float(p.item), 0.0f);
+    q.thr[i] = make_float4(p.ps.throughput.x, p.ps.throughput.y, p.ps.throughput.z, __uint_as_float(p.item));
+    q.rng[i] = make_float2(__uint_as_float((uint32_t)p.rng.state), __uint_as_float((uint32_t)(p.rng.state >> 32)));
     q.hit[i] = make_float4(tv.best.t, __int_as_float(tv.best.id), __int_as_float(tv.best.slot), __int_as_float(tv.floor_id));
 }
 
@@ -108,6 +112,12 @@ RT_DEV uint32_t wave_append(uint32_t *counter, bool keep) {
 
 template <bool STATS>
 RT_DEV void flush_counters(const Counters &cnt, uint32_t paths, unsigned long long *stats) {
+    if (kTimers && !STATS) {
+        for (int i = 0; i < RT_N_REGIONS; ++i) {
+            uint32_t w = wave_sum(cnt.region[i]);
+            if ((threadIdx.x & 63u) == 0 && w) atomicAdd(&stats[32 + i], (unsigned long long)w);
+        }
+    }
     if (!STATS) return;
     uint32_t vals[31];
     vals[0] = paths;
@@ -136,10 +146,18 @@ __global__ void __launch_bounds__(256) wf_generate_kernel(DScene sc, WfArgs w, P
     const WfCounters *c = ctr + (it % RT_WF_RING);
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t shard = (blockIdx.x * blockDim.x) / w.cap, off0 = (blockIdx.x * blockDim.x) - shard * w.cap;   // block-uniform
-    const uint32_t item_head = c->sh[0].item_head;
-    uint32_t room_before = 0;                         // free entries in the shards before this one
-    for (uint32_t t = 0; t < shard; ++t) room_before += w.cap - c->sh[t].n_surv;
     const uint32_t n_surv = c->sh[shard].n_surv;
+    if (off0 != 0 && off0 + blockDim.x <= n_surv) return;   // block-uniform: only survivors here (most blocks in steady state)
+    __shared__ uint32_t s_sum[3];
+    if (threadIdx.x < 64u) {                          // one wave sums the shard counters (64 lines, one load each)
+        const uint32_t sv = c->sh[threadIdx.x].n_surv;
+        const uint32_t before = wave_sum(threadIdx.x < shard ? w.cap - sv : 0u);
+        const uint32_t all = wave_sum(w.cap - sv), surv = wave_sum(sv);
+        if (threadIdx.x == 0) { s_sum[0] = before; s_sum[1] = all; s_sum[2] = surv; }
+    }
+    __syncthreads();
+    const uint32_t item_head = c->sh[0].item_head;
+    const uint32_t room_before = s_sum[0];            // free entries in the shards before this one
     const uint32_t left = w.n_items - item_head;
     const uint32_t left_here = left > room_before ? left - room_before : 0u;
     const uint32_t room = w.cap - n_surv;
@@ -148,8 +166,7 @@ __global__ void __launch_bounds__(256) wf_generate_kernel(DScene sc, WfArgs w, P
         WfShard *n = &ctr[(it + 1u) % RT_WF_RING].sh[shard];
         n->count_in = n_surv + n_new; n->n_surv = 0; n->cursor = 0;
         if (shard == 0) {
-            uint32_t room_all = 0, surv_all = 0;
-            for (uint32_t t = 0; t < RT_WF_SHARDS; ++t) { room_all += w.cap - c->sh[t].n_surv; surv_all += c->sh[t].n_surv; }
+            const uint32_t room_all = s_sum[1], surv_all = s_sum[2];
             const uint32_t issued = room_all < left ? room_all : left;
             n->item_head = item_head + issued;
             status[0] = surv_all + issued; status[1] = item_head + issued; status[2] = it + 1u;
@@ -175,7 +192,9 @@ __global__ void __launch_bounds__(256) wf_generate_kernel(DScene sc, WfArgs w, P
     if (start) {
         p.pixel = (uint32_t)y * (uint32_t)w.a.width + (uint32_t)x;
         rts::path_rng(p.rng, w.a.seed, p.pixel, p.sample);
+        RG_BEGIN(RG_CAMERA);
         p.ps.ray = camera_ray(sc, w.a, x, y, p.pixel, p.sample, p.rng);
+        RG_END(RG_CAMERA);
         p.ps.throughput = v3(1.0f, 1.0f, 1.0f);
         p.ps.radiance = v3(0.0f, 0.0f, 0.0f);
         p.ps.depth = w.a.max_depth;
@@ -183,11 +202,14 @@ __global__ void __launch_bounds__(256) wf_generate_kernel(DScene sc, WfArgs w, P
         const bool walk = begin_trace<STATS>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt);
         store_entry(nxt, e, p, tv, walk);
     }
-    if (STATS) flush_counters<STATS>(cnt, inside ? 1u : 0u, stats);
+    if (STATS || kTimers) flush_counters<STATS>(cnt, inside ? 1u : 0u, stats);
 }
 
 /* ------------------------------------------------------------------ traverse */
 
+#ifndef RT_WF_SORT
+#define RT_WF_SORT 1           // shade: deal a block's entries to its threads in material order
+#endif
 #ifndef RT_WF_FETCH_MIN
 #define RT_WF_FETCH_MIN 20     // refill when at least this many lanes of the wave are idle
 #endif
@@ -199,12 +221,15 @@ __global__ void __launch_bounds__(256) wf_generate_kernel(DScene sc, WfArgs w, P
 // takes the next entries of the pool for them, so the node loop runs with most lanes busy.  Inside,
 // "while-while": node steps for everyone standing on an inner node, leaf steps once enough lanes
 // stand on a leaf (RT_LEAF_MIN) or nobody is left on an inner node.
+#ifndef RT_WF_TRAV_WAVES
+#define RT_WF_TRAV_WAVES 1
+#endif
 template <bool STATS>
-__global__ void __launch_bounds__(256) wf_traverse_kernel(DScene sc, PathQ q, WfCounters *ctr, uint32_t it, uint32_t cap, unsigned long long *stats) {
-    extern __shared__ uint2 lds_stack[];
+__global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DScene sc, PathQ q, WfCounters *ctr, uint32_t it, uint32_t cap, uint32_t lds_depth,
+                                                          StackEntry *ovf, unsigned long long *stats) {
+    extern __shared__ StackEntry lds_stack[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    uint2 *stack = lds_stack + tid;
-    const uint32_t stride = blockDim.x;
+    const Stack stack{lds_stack + tid, blockDim.x, lds_depth, ovf ? ovf + (size_t)blockIdx.x * blockDim.x + tid : nullptr, gridDim.x * blockDim.x};
     const uint32_t shard = blockIdx.x % RT_WF_SHARDS;
     WfShard *c = &ctr[it % RT_WF_RING].sh[shard];
     const uint32_t n = c->count_in, shard_base = shard * cap;
@@ -223,6 +248,7 @@ __global__ void __launch_bounds__(256) wf_traverse_kernel(DScene sc, PathQ q, Wf
         const uint32_t n_idle = (uint32_t)__popcll(m_idle);
         if (n_idle == 64u && exhausted) break;
         if (!exhausted && n_idle >= RT_WF_FETCH_MIN) {
+            RG_BEGIN(RG_FETCH);
             if (w_next >= w_end) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&c->cursor, RT_WF_CHUNK);
@@ -255,34 +281,42 @@ __global__ void __launch_bounds__(256) wf_traverse_kernel(DScene sc, PathQ q, Wf
                 }
             }
             w_next += n_idle < avail ? n_idle : avail;
+            RG_END(RG_FETCH);
             if (__ballot(idx >= 0) == 0ull) continue;   // nothing to walk among what was fetched
         }
         // node steps
         phase_count<STATS>(cnt, PH_NODE, idx >= 0 && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
-        if (idx >= 0 && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY) trav_node_step<STATS>(sc, T_MIN, tv, stack, stride, cnt);
+        RG_BEGIN(RG_NODE);
+        if (idx >= 0 && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY) trav_node_step<STATS>(sc, T_MIN, tv, stack, cnt);
+        RG_END(RG_NODE);
         const bool at_leaf = idx >= 0 && tv.ref < 0;
         const unsigned long long m_leaf = __ballot(at_leaf);
         const unsigned long long m_node = __ballot(idx >= 0 && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
         if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
             phase_count<STATS>(cnt, PH_LEAF, at_leaf);
-            if (at_leaf) trav_leaf_step<STATS>(sc, r, T_MIN, tv, stack, stride, cnt);
+            RG_BEGIN(RG_LEAF);
+            if (at_leaf) trav_leaf_step<STATS>(sc, r, T_MIN, tv, stack, cnt);
+            RG_END(RG_LEAF);
         }
         if (idx >= 0 && tv.ref == RT_BVH_EMPTY) {
             q.hit[idx] = make_float4(tv.best.t, __int_as_float(tv.best.id), __int_as_float(tv.best.slot), __int_as_float(tv.floor_id));
             idx = -1;
         }
     }
-    if (STATS) flush_counters<STATS>(cnt, 0u, stats);
+    if (STATS || kTimers) flush_counters<STATS>(cnt, 0u, stats);
 }
 
 /* ------------------------------------------------------------------ shade */
 
 // One thread per pool entry: finish the hit, run ray_color's body, start the next ray (everything of
 // world.hit() that comes before the BVH walk), append the survivor to the next buffer.
+#ifndef RT_WF_SHADE_WAVES
+#define RT_WF_SHADE_WAVES 1
+#endif
 template <bool STATS>
-__global__ void __launch_bounds__(256) wf_shade_kernel(DScene sc, WfArgs w, PathQ cur, PathQ nxt, WfCounters *ctr, uint32_t it,
+__global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene sc, WfArgs w, PathQ cur, PathQ nxt, WfCounters *ctr, uint32_t it,
                                                        float4 *__restrict__ samples, unsigned long long *stats, uint32_t *pixel_rays) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t shard = (blockIdx.x * blockDim.x) / w.cap, off0 = (blockIdx.x * blockDim.x) - shard * w.cap;   // block-uniform
     WfShard *c = &ctr[it % RT_WF_RING].sh[shard];
     const uint32_t n = c->count_in;
@@ -295,32 +329,84 @@ __global__ void __launch_bounds__(256) wf_shade_kernel(DScene sc, WfArgs w, Path
     tv.ref = RT_BVH_EMPTY; tv.sp = 0; tv.best.t = 0.0f; tv.best.id = -1; tv.best.slot = 0; tv.floor_id = -1;
     uint32_t flags = 0;
     float4 d = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#if RT_WF_SORT
+    // Block-local sort by what the bounce will do (material type / miss / nothing): the 256 entries of
+    // the block are dealt to the threads in key order, so most waves run one branch of ray_color's
+    // material switch instead of all of them.  Which thread takes which entry changes nothing else.
+    {
+        __shared__ uint32_t s_count[8][4];
+        __shared__ uint16_t s_perm[256];
+        const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+        uint32_t key = 7u;
+        if (off0 + threadIdx.x < n) {
+            const uint32_t f = __float_as_uint(cur.ray_d[i].w);
+            if (f & WF_ALIVE) {
+                const float4 h = cur.hit[i];
+                const int32_t id = f2i(h.y), slot = f2i(h.z);
+                if (id < 0) key = 6u;
+                else {
+                    const int mat = slot < 0 ? f2i(sc.media[2 * (uint32_t)(-slot - 1) + 1].y) : f2i(sc.slots[4 * (size_t)slot + 1].y);
+                    key = (uint32_t)f2i(sc.materials[2 * mat].x) & 7u;
+                    if (key > 5u) key = 5u;
+                }
+            }
+        }
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+            const unsigned long long m = __ballot(key == k);
+            if (key == k) rank = (uint32_t)__popcll(m & ((1ull << ln) - 1ull));
+            if (ln == 0) s_count[k][wv] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        uint32_t before = 0;     // entries with a smaller key, or the same key in an earlier wave
+        for (uint32_t k = 0; k < 8u; ++k)
+            for (uint32_t v = 0; v < 4u; ++v)
+                if (k < key || (k == key && v < wv)) before += s_count[k][v];
+        s_perm[before + rank] = (uint16_t)threadIdx.x;
+        __syncthreads();
+        i = blockIdx.x * blockDim.x + s_perm[threadIdx.x];
+        if (off0 + s_perm[threadIdx.x] < n) { d = cur.ray_d[i]; flags = __float_as_uint(d.w); }
+    }
+#else
     if (off0 + threadIdx.x < n) { d = cur.ray_d[i]; flags = __float_as_uint(d.w); }
+#endif
     const bool alive = (flags & WF_ALIVE) != 0u;
     phase_count<STATS>(cnt, PH_SHADE, alive);
     if (alive) {
-        const float4 o = cur.ray_o[i], th = cur.thr[i], ra = cur.rad[i], rg = cur.rng[i], h = cur.hit[i];
+        RG_BEGIN(RG_LOAD);
+        const float4 o = cur.ray_o[i], th = cur.thr[i], h = cur.hit[i];
+        const float2 rg = cur.rng[i];
         p.ps.ray.o = v3(o.x, o.y, o.z); p.ps.ray.d = v3(d.x, d.y, d.z); p.ps.ray.time = o.w;
-        p.ps.throughput = v3(th.x, th.y, th.z); p.pixel = __float_as_uint(th.w);
-        p.ps.radiance = v3(ra.x, ra.y, ra.z); p.sample = __float_as_uint(ra.w);
+        p.ps.throughput = v3(th.x, th.y, th.z); p.item = __float_as_uint(th.w);
+        p.ps.radiance = v3(0.0f, 0.0f, 0.0f);
         p.ps.depth = (int)(flags & WF_DEPTH_MASK);
-        p.item = __float_as_uint(rg.z);
+        int px, py;
+        item_pixel(w, p.item, &px, &py, &p.sample);
+        p.pixel = (uint32_t)py * (uint32_t)w.a.width + (uint32_t)px;
         p.rng.state = ((uint64_t)__float_as_uint(rg.y) << 32) | (uint64_t)__float_as_uint(rg.x);
         p.rng.inc = (((((uint64_t)p.pixel << 24) ^ (uint64_t)p.sample)) << 1u) | 1u;   // rts::path_rng's stream
         tv.best.t = h.x; tv.best.id = f2i(h.y); tv.best.slot = f2i(h.z); tv.floor_id = f2i(h.w);
+        RG_END(RG_LOAD);
         finish_trace<STATS>(sc, p.ps.ray, 0.001f, INFINITY, tv, cnt);
+        RG_BEGIN(RG_SHADE_ALL);
         const bool cont = shade_hit<STATS>(sc, p.ps, tv.best, background, p.rng, cnt);
+        RG_END(RG_SHADE_ALL);
         if (cont && p.ps.depth > 0) survive = true;
         else samples[p.item] = make_float4(p.ps.radiance.x, p.ps.radiance.y, p.ps.radiance.z, 0.0f);
     }
     phase_count<STATS>(cnt, PH_BEGIN, survive);
     if (survive) {
         if (STATS) { cnt.rays += 1; if (pixel_rays) atomicAdd(&pixel_rays[p.pixel], 1u); }
+        RG_BEGIN(RG_BEGIN_ALL);
         walk = begin_trace<STATS>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt);
+        RG_END(RG_BEGIN_ALL);
     }
+    RG_BEGIN(RG_STORE);
     const uint32_t pos = shard * w.cap + wave_append(&c->n_surv, survive);
     if (survive) store_entry(nxt, pos, p, tv, walk);
-    if (STATS) flush_counters<STATS>(cnt, 0u, stats);
+    RG_END(RG_STORE);
+    if (STATS || kTimers) flush_counters<STATS>(cnt, 0u, stats);
 }
 
 /* ------------------------------------------------------------------ fold */

@@ -2,6 +2,8 @@
 usage: isa_profile.py dev.s rt_kernels.h"""
 import re, sys, collections
 asm, src = sys.argv[1], sys.argv[2]
+kname = sys.argv[3] if len(sys.argv) > 3 else "_ZN3rtk13render_kernelILb0EE"
+kfn = sys.argv[4] if len(sys.argv) > 4 else "render_kernel"
 # function line ranges in rt_kernels.h: a line starting a function = "RT_DEV ... name(" or "__global__"
 starts = []
 lines = open(src).read().split("\n")
@@ -21,7 +23,7 @@ def fn_of(line):
 inner = collections.Counter(); top = collections.Counter(); allv = 0
 in_k = False; chain = []
 for l in open(asm):
-    if l.startswith("_ZN3rtk13render_kernelILb0EE"): in_k = True; continue
+    if l.startswith(kname): in_k = True; continue
     if in_k and l.startswith(".Lfunc_end"): break
     if not in_k: continue
     if "\t.loc\t" in l:
@@ -38,10 +40,10 @@ for l in open(asm):
     if other and other[0] in ("rt_portable_math.h", "rt_seed_schedule.h"): innermost = other[0] + "<-" + innermost
     inner[innermost] += 1
     # top = the callee directly under render_kernel
-    t = "render_kernel"
+    t = kfn
     for k in reversed(ks):
-        if k != "render_kernel": t = k; break
+        if k != kfn and k != "?": t = k; break
     top[t] += 1
-print("VALU instructions in render_kernel<false>:", allv)
+print("VALU instructions in", kname, allv)
 print("-- by callee of render_kernel"); [print("%6d %s" % (c, n)) for n, c in top.most_common()]
 print("-- by innermost function"); [print("%6d %s" % (c, n)) for n, c in inner.most_common(40)]

@@ -1,0 +1,30 @@
+"""usage: regions.py WORKLOAD SPP — where the counting variant's waves spend their cycles (rt_stats.region_cycles)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, rtiow_loader
+rt = rtiow_loader.load()
+wl, spp = sys.argv[1], int(sys.argv[2])
+scene, params, camera, sampler = rt.configs.build(wl, samples_per_pixel=spp)
+gpu = rt.backend.HipBackend(0); gpu.upload_scene(scene.flatten()); gpu.upload_sampler(sampler)
+if "--child" in sys.argv:
+    gpu.render(params, camera); sys.exit(0)
+_, st = gpu.render(params, camera, stats=True)
+# the timers come from the product kernels of a -DRT_REGION_TIMERS=1 build, printed on stderr by the library
+import subprocess, tempfile
+err = subprocess.run([sys.executable, os.path.abspath(__file__), wl, str(spp), "--child"], capture_output=True, text=True).stderr
+line_ = [l for l in err.splitlines() if l.startswith("[rt-regions]")]
+if not line_: sys.exit("library was not built with -DRT_REGION_TIMERS=1:\n" + err[-2000:])
+st["region_cycles"] = [int(x) for x in line_[-1].split()[1:]]
+names = "LOAD FINISH RECORD TEXTURE EMIT METAL DIEL ISO LAMBERT L_LIGHTS L_COSINE L_PDF B_MEDIA B_RECTS B_ALWAYS B_REST STORE NODE LEAF FETCH CAMERA SHADE_ALL BEGIN_ALL".split()
+rc = dict(zip(names, st["region_cycles"]))
+rays = st["rays"]
+print(wl, "rays", rays, "paths", st["paths"])
+top_s = ["LOAD", "SHADE_ALL", "BEGIN_ALL", "STORE"]; top_t = ["FETCH", "NODE", "LEAF"]
+tot = sum(rc[k] for k in top_s + top_t + ["CAMERA"])
+def line(k, indent=""): print("%s%-10s %6.2f%%  %8.1f wave-cycles/ray" % (indent, k, 100.0 * rc[k] / tot, rc[k] / rays))
+print("-- shade kernel"); [line(k) for k in top_s]
+print("   inside shade_hit:"); [line(k, "   ") for k in ("RECORD", "EMIT", "METAL", "DIEL", "ISO", "LAMBERT")]
+print("      inside lambertian:"); [line(k, "      ") for k in ("TEXTURE", "L_LIGHTS", "L_COSINE", "L_PDF")]
+print("   inside begin_trace:"); [line(k, "   ") for k in ("B_MEDIA", "B_ALWAYS")]
+print("-- traverse kernel"); [line(k) for k in top_t]
+print("-- generate: camera"); line("CAMERA")
