@@ -165,8 +165,6 @@ typedef struct rt_stats {
        4 begin-trace): phase_slots += 64 each time a wave runs the phase, phase_lanes += lanes working in it. */
     uint64_t phase_lanes[5];
     uint64_t phase_slots[5];
-    /* Cycles waves spent in code regions of the kernels (profiling aid; indices = rtk::RG_* in rt_kernels.h) */
-    uint64_t region_cycles[24];
 } rt_stats;
 
 /* ------------------------------------------------------------------- entry points */

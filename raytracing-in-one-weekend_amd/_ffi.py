@@ -82,16 +82,14 @@ class rt_stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64), ("box_tests", C.c_uint64),
                 ("prim_tests", C.c_uint64 * 6), ("medium_tests", C.c_uint64), ("light_pdf_evals", C.c_uint64),
                 ("shades", C.c_uint64 * 5), ("tex_evals", C.c_uint64 * 4), ("accepted_hits", C.c_uint64),
-                ("phase_lanes", C.c_uint64 * 5), ("phase_slots", C.c_uint64 * 5),
-                ("region_cycles", C.c_uint64 * 24)]
+                ("phase_lanes", C.c_uint64 * 5), ("phase_slots", C.c_uint64 * 5)]
 
     def as_dict(self):
         return {"paths": self.paths, "rays": self.rays, "node_visits": self.node_visits, "box_tests": self.box_tests,
                 "prim_tests": list(self.prim_tests), "medium_tests": self.medium_tests,
                 "light_pdf_evals": self.light_pdf_evals, "shades": list(self.shades),
                 "tex_evals": list(self.tex_evals), "accepted_hits": self.accepted_hits,
-                "phase_lanes": list(self.phase_lanes), "phase_slots": list(self.phase_slots),
-                "region_cycles": list(self.region_cycles)}
+                "phase_lanes": list(self.phase_lanes), "phase_slots": list(self.phase_slots)}
 
 
 class rtg_node(C.Structure):

@@ -34,8 +34,10 @@ struct rt_ctx {
     float4 *wf_samples = nullptr; size_t wf_samples_entries = 0;
     WfCounters *wf_ctr = nullptr;                               // ring + status words behind it
     StackEntry *wf_ovf = nullptr;  size_t wf_ovf_entries = 0;      // traversal stack overflow (entries beyond the LDS part)
-    uint32_t *wf_host_status = nullptr;                         // pinned, 2 x 4 words
-    hipEvent_t wf_event[2] = {nullptr, nullptr};
+    uint32_t *wf_host_status = nullptr;                         // pinned, per pipeline 2 x 4 words
+    hipStream_t wf_stream[4] = {};                              // one per pipeline (render_wavefront)
+    hipEvent_t wf_event[4][2] = {};
+    hipEvent_t wf_fork = nullptr, wf_join[4] = {};
 };
 
 namespace {
@@ -91,6 +93,7 @@ size_t env_size(const char *name, size_t dflt, size_t lo, size_t hi) {
     return dflt;
 }
 
+constexpr int kMaxPipes = 4;
 constexpr size_t kEntryBytes = 72;   // rt_wavefront.h: 4 float4 + 1 float2 per pool entry
 
 PathQ pool_buffer(rt_ctx *ctx, int which) {
@@ -110,10 +113,13 @@ void magic_div(uint32_t d, uint32_t *m, uint32_t *k) {
     *m = (uint32_t)(((1ull << *k) / d) + 1);
 }
 
-// The streaming pipeline of rt_wavefront.h for one rt_render call.  Samples are rendered in
-// batches that fit the sample buffer; within a batch the host enqueues iterations
-// (traverse, shade, generate) eight at a time and looks at the pool's status two groups behind,
-// so the GPU always has work queued while the host decides whether the pool has drained.
+// The streaming pipeline of rt_wavefront.h for one rt_render call.  Samples are rendered in batches
+// that fit the sample buffer.  A batch's items are split over RT_WF_PIPES independent pipelines (own
+// pool, counters and HIP stream): traverse is bound by memory latency and LDS, shade by registers,
+// so kernels of two pipelines running side by side on a CU use what the other leaves idle.
+// Per pipeline the host enqueues iterations (traverse, shade, generate) eight at a time and looks at
+// the pool's status two groups behind, so the GPU always has work queued while the host decides
+// whether the pool has drained.
 template <bool STATS>
 int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p, float4 *d_out, uint32_t *d_rays, hipStream_t stream) {
     const uint32_t tiles_x = (uint32_t)(a.x1 - a.x0 + 7) / 8u, tiles_y = (uint32_t)(a.y1 - a.y0 + 7) / 8u;
@@ -124,31 +130,40 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     size_t spp_batch_max = cap_entries / per_sample;
     if (spp_batch_max * per_sample >= (1ull << 32)) spp_batch_max = ((1ull << 32) - 1) / per_sample;
     if (spp_batch_max > (size_t)a.spp_count) spp_batch_max = (size_t)a.spp_count;
-    const size_t pool_want = (size_t)1 << env_size("RT_WF_POOL_LOG2", 22, 14, 26);
-    // workspace
+    const bool has_bvh = ctx->sc.root_ref != RT_BVH_EMPTY;
+    const size_t shard_q = (size_t)RT_WF_SHARDS * 256;    // pool sizes are multiples of this
     const size_t need_samples = spp_batch_max * per_sample;
+    int n_pipes = (int)env_size("RT_WF_PIPES", 2, 1, kMaxPipes);
+    if (need_samples < 4 * shard_q || n_tiles < 2u) n_pipes = 1;
+    size_t pool_want = ((size_t)1 << env_size("RT_WF_POOL_LOG2", 23, 14, 26)) / (size_t)n_pipes;   // per pipeline
+    pool_want = pool_want / shard_q * shard_q;
+    if (pool_want < shard_q) pool_want = shard_q;
+    // workspace
     if (ctx->wf_samples_entries < need_samples) {
         if (ctx->wf_samples) { (void)hipStreamSynchronize(stream); (void)hipFree(ctx->wf_samples); ctx->wf_samples = nullptr; ctx->wf_samples_entries = 0; }
         HIP_TRY(ctx, hipMalloc((void **)&ctx->wf_samples, need_samples * 16));
         ctx->wf_samples_entries = need_samples;
     }
-    const size_t shard_q = (size_t)RT_WF_SHARDS * 256;    // pool sizes are multiples of this
-    size_t pool = need_samples < pool_want ? (need_samples + shard_q - 1) / shard_q * shard_q : pool_want;
+    const size_t per_pipe_items = (need_samples + n_pipes - 1) / n_pipes;
+    size_t pool = per_pipe_items < pool_want ? (per_pipe_items + shard_q - 1) / shard_q * shard_q : pool_want;
     if (ctx->wf_pool_entries < pool) {
-        if (ctx->wf_pool) { (void)hipStreamSynchronize(stream); (void)hipFree(ctx->wf_pool); ctx->wf_pool = nullptr; ctx->wf_pool_entries = 0; }
-        HIP_TRY(ctx, hipMalloc(&ctx->wf_pool, pool * 2 * kEntryBytes));
+        if (ctx->wf_pool) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->wf_pool); ctx->wf_pool = nullptr; ctx->wf_pool_entries = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->wf_pool, pool * 2 * kEntryBytes * kMaxPipes));
         ctx->wf_pool_entries = pool;
     }
     if (!ctx->wf_ctr) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->wf_ctr, (RT_WF_RING + 1) * sizeof(WfCounters)));   // ring + one block for the status words
-        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->wf_host_status, 2 * 4 * sizeof(uint32_t), hipHostMallocDefault));
-        for (hipEvent_t &ev : ctx->wf_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->wf_ctr, kMaxPipes * (RT_WF_RING + 1) * sizeof(WfCounters)));   // per pipe: ring + one block for the status words
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->wf_host_status, kMaxPipes * 2 * 4 * sizeof(uint32_t), hipHostMallocDefault));
+        for (int q = 0; q < kMaxPipes; ++q) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->wf_stream[q], hipStreamNonBlocking));
+            for (hipEvent_t &ev : ctx->wf_event[q]) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_join[q], hipEventDisableTiming));
+        }
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming));
     }
-    uint32_t *d_status = reinterpret_cast<uint32_t *>(ctx->wf_ctr + RT_WF_RING);
-    const PathQ Q[2] = {pool_buffer(ctx, 0), pool_buffer(ctx, 1)};
-    const bool has_bvh = ctx->sc.root_ref != RT_BVH_EMPTY;
     // traversal stack: the first lds_depth entries of every lane in LDS, the (rarely reached) rest in HBM
-    const uint32_t lds_depth = (uint32_t)env_size("RT_WF_LDS_DEPTH", 20, 1, 64) < ctx->stack_depth ? (uint32_t)env_size("RT_WF_LDS_DEPTH", 20, 1, 64) : ctx->stack_depth;
+    const uint32_t lds_want = (uint32_t)env_size("RT_WF_LDS_DEPTH", 20, 1, 64);
+    const uint32_t lds_depth = lds_want < ctx->stack_depth ? lds_want : ctx->stack_depth;
     const size_t lds = (size_t)lds_depth * 256 * sizeof(StackEntry);
     int per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_traverse_kernel<STATS>, 256, lds));
@@ -159,64 +174,105 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         int by_regs = 512 / regs > 8 ? 8 : 512 / regs;
         int by_lds = lds ? (int)((160 * 1024) / lds) : 8;
         int mine = by_regs < by_lds ? by_regs : by_lds;
-        if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] traverse: numRegs %d lds %zu runtime per_cu %d, computed %d\n", fa.numRegs, lds, per_cu, mine);
+        if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] traverse: numRegs %d lds %zu runtime per_cu %d, computed %d, pipes %d\n", fa.numRegs, lds, per_cu, mine, n_pipes);
         if (mine > per_cu) per_cu = mine;
         per_cu = (int)env_size("RT_WF_TRAV_BLOCKS", (size_t)per_cu, 1, 16);
     }
     if (per_cu < 1) per_cu = 1;
     const unsigned trav_blocks = ((unsigned)(per_cu * ctx->prop.multiProcessorCount) + RT_WF_SHARDS - 1) / RT_WF_SHARDS * RT_WF_SHARDS;
-    const size_t ovf_entries = (size_t)(ctx->stack_depth - lds_depth) * trav_blocks * 256;
-    if (ovf_entries > ctx->wf_ovf_entries) {
-        if (ctx->wf_ovf) { (void)hipStreamSynchronize(stream); (void)hipFree(ctx->wf_ovf); ctx->wf_ovf = nullptr; ctx->wf_ovf_entries = 0; }
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->wf_ovf, ovf_entries * sizeof(StackEntry)));
-        ctx->wf_ovf_entries = ovf_entries;
+    const size_t ovf_per_pipe = (size_t)(ctx->stack_depth - lds_depth) * trav_blocks * 256;
+    if (ovf_per_pipe * kMaxPipes > ctx->wf_ovf_entries) {
+        if (ctx->wf_ovf) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->wf_ovf); ctx->wf_ovf = nullptr; ctx->wf_ovf_entries = 0; }
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->wf_ovf, ovf_per_pipe * kMaxPipes * sizeof(StackEntry)));
+        ctx->wf_ovf_entries = ovf_per_pipe * kMaxPipes;
     }
-    StackEntry *d_ovf = ovf_entries ? ctx->wf_ovf : nullptr;
     unsigned long long *d_stats = (STATS || kTimers) ? ctx->d_stats : nullptr;
     if (STATS || kTimers) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 64 * sizeof(unsigned long long), stream));
 
-    WfArgs w{};
-    w.a = a;
-    w.tiles_x = tiles_x; w.n_tiles = n_tiles;
-    magic_div(tiles_x, &w.tx_m, &w.tx_k);
+    struct Pipe {
+        hipStream_t s;
+        PathQ Q[2];
+        WfCounters *ctr;
+        uint32_t *d_status, *h_status;
+        StackEntry *ovf;
+        WfArgs w;
+        uint32_t it, groups;
+        unsigned pool_blocks;
+        bool drained;
+    } pipe[kMaxPipes];
+    for (int q = 0; q < n_pipes; ++q) {
+        Pipe &P = pipe[q];
+        P.s = n_pipes == 1 ? stream : ctx->wf_stream[q];
+        P.Q[0] = pool_buffer(ctx, 2 * q); P.Q[1] = pool_buffer(ctx, 2 * q + 1);
+        P.ctr = ctx->wf_ctr + (size_t)q * (RT_WF_RING + 1);
+        P.d_status = reinterpret_cast<uint32_t *>(P.ctr + RT_WF_RING);
+        P.h_status = ctx->wf_host_status + (size_t)q * 8;
+        P.ovf = ovf_per_pipe ? ctx->wf_ovf + (size_t)q * ovf_per_pipe : nullptr;
+        P.w = WfArgs{};
+        P.w.a = a;
+        P.w.tiles_x = tiles_x; P.w.n_tiles = n_tiles;
+        magic_div(tiles_x, &P.w.tx_m, &P.w.tx_k);
+    }
     for (int32_t s0 = 0; s0 < a.spp_count; s0 += (int32_t)spp_batch_max) {
-        w.spp_batch = (uint32_t)((size_t)(a.spp_count - s0) < spp_batch_max ? (size_t)(a.spp_count - s0) : spp_batch_max);
-        w.sample0 = (uint32_t)(a.spp_begin + s0);
-        w.n_items = (uint32_t)(per_sample * w.spp_batch);
-        magic_div(w.spp_batch, &w.spp_m, &w.spp_k);
-        const size_t items_up = ((size_t)w.n_items + shard_q - 1) / shard_q * shard_q;
-        w.pool = (uint32_t)(items_up < ctx->wf_pool_entries ? items_up : ctx->wf_pool_entries);
-        if (w.pool > pool_want) w.pool = (uint32_t)pool_want;
-        w.cap = w.pool / RT_WF_SHARDS;
-        const unsigned pool_blocks = w.pool / 256u;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->wf_ctr, 0, (RT_WF_RING + 1) * sizeof(WfCounters), stream));
-        ctx->wf_host_status[0] = ctx->wf_host_status[4] = 1u;   // "not drained"
-        ctx->wf_host_status[1] = ctx->wf_host_status[5] = 0u;
-        uint32_t it = 0;
-        hipLaunchKernelGGL(wf_generate_kernel<STATS>, dim3(pool_blocks), dim3(256), 0, stream, ctx->sc, w, Q[1], ctx->wf_ctr, it,
-                           ctx->wf_samples, d_status, d_stats, d_rays);
-        bool drained = false;
-        for (uint32_t group = 0; !drained; ++group) {
-            if (group >= 2) {   // look at the status copied after group - 2
-                HIP_TRY(ctx, hipEventSynchronize(ctx->wf_event[group & 1]));
-                const uint32_t *hs = ctx->wf_host_status + 4 * (group & 1);
-                if (hs[0] == 0u && hs[1] == w.n_items) { drained = true; break; }
-                if (p->cancel && *p->cancel) { (void)hipStreamSynchronize(stream); return fail(ctx, RT_E_CANCELLED, "cancelled"); }
-            }
-            for (int k = 0; k < 8; ++k) {
-                ++it;
-                const PathQ &cur = Q[it & 1], &nxt = Q[(it + 1) & 1];
-                if (has_bvh) hipLaunchKernelGGL(wf_traverse_kernel<STATS>, dim3(trav_blocks), dim3(256), lds, stream, ctx->sc, cur, ctx->wf_ctr, it, w.cap, lds_depth, d_ovf, d_stats);
-                hipLaunchKernelGGL(wf_shade_kernel<STATS>, dim3(pool_blocks), dim3(256), 0, stream, ctx->sc, w, cur, nxt, ctx->wf_ctr, it,
-                                   ctx->wf_samples, d_stats, d_rays);
-                hipLaunchKernelGGL(wf_generate_kernel<STATS>, dim3(pool_blocks), dim3(256), 0, stream, ctx->sc, w, nxt, ctx->wf_ctr, it,
-                                   ctx->wf_samples, d_status, d_stats, d_rays);
-            }
-            HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host_status + 4 * (group & 1), d_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(ctx, hipEventRecord(ctx->wf_event[group & 1], stream));
+        const uint32_t spp_batch = (uint32_t)((size_t)(a.spp_count - s0) < spp_batch_max ? (size_t)(a.spp_count - s0) : spp_batch_max);
+        if (n_pipes > 1) {   // the pipelines start after whatever the caller queued before this call
+            HIP_TRY(ctx, hipEventRecord(ctx->wf_fork, stream));
+            for (int q = 0; q < n_pipes; ++q) HIP_TRY(ctx, hipStreamWaitEvent(pipe[q].s, ctx->wf_fork, 0));
         }
-        hipLaunchKernelGGL(wf_fold_kernel, dim3((n_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, w, ctx->wf_samples, d_out);
+        for (int q = 0; q < n_pipes; ++q) {
+            Pipe &P = pipe[q];
+            WfArgs &w = P.w;
+            w.spp_batch = spp_batch;
+            w.sample0 = (uint32_t)(a.spp_begin + s0);
+            magic_div(spp_batch, &w.spp_m, &w.spp_k);
+            // pipe q renders tiles [t0, t1): whole tiles, so an item's index is the same with any number of pipes
+            const uint32_t t0 = (uint32_t)((uint64_t)n_tiles * q / n_pipes), t1 = (uint32_t)((uint64_t)n_tiles * (q + 1) / n_pipes);
+            w.item0 = t0 * spp_batch * 64u;
+            w.n_items = (t1 - t0) * spp_batch * 64u;
+            const size_t items_up = ((size_t)w.n_items + shard_q - 1) / shard_q * shard_q;
+            w.pool = (uint32_t)(items_up < ctx->wf_pool_entries ? items_up : ctx->wf_pool_entries);
+            if (w.pool > pool_want) w.pool = (uint32_t)pool_want;
+            w.cap = w.pool / RT_WF_SHARDS;
+            P.pool_blocks = w.pool / 256u;
+            HIP_TRY(ctx, hipMemsetAsync(P.ctr, 0, (RT_WF_RING + 1) * sizeof(WfCounters), P.s));
+            P.it = 0; P.groups = 0; P.drained = false;
+            hipLaunchKernelGGL(wf_generate_kernel<STATS>, dim3(P.pool_blocks), dim3(256), 0, P.s, ctx->sc, w, P.Q[1], P.ctr, P.it,
+                               ctx->wf_samples, P.d_status, d_stats, d_rays);
+        }
+        for (int live = n_pipes; live > 0;) {
+            for (int q = 0; q < n_pipes; ++q) {
+                Pipe &P = pipe[q];
+                if (P.drained) continue;
+                const uint32_t group = P.groups;
+                if (group >= 2) {   // look at the status copied after group - 2
+                    HIP_TRY(ctx, hipEventSynchronize(ctx->wf_event[q][group & 1]));
+                    const uint32_t *hs = P.h_status + 4 * (group & 1);
+                    if (hs[0] == 0u && hs[1] == P.w.n_items) { P.drained = true; --live; continue; }
+                    if (p->cancel && *p->cancel) { (void)hipDeviceSynchronize(); return fail(ctx, RT_E_CANCELLED, "cancelled"); }
+                }
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t it = ++P.it;
+                    const PathQ &cur = P.Q[it & 1], &nxt = P.Q[(it + 1) & 1];
+                    if (has_bvh) hipLaunchKernelGGL(wf_traverse_kernel<STATS>, dim3(trav_blocks), dim3(256), lds, P.s, ctx->sc, cur, P.ctr, it, P.w.cap,
+                                                    lds_depth, P.ovf, d_stats);
+                    hipLaunchKernelGGL(wf_shade_kernel<STATS>, dim3(P.pool_blocks), dim3(256), 0, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
+                                       ctx->wf_samples, d_stats, d_rays);
+                    hipLaunchKernelGGL(wf_generate_kernel<STATS>, dim3(P.pool_blocks), dim3(256), 0, P.s, ctx->sc, P.w, nxt, P.ctr, it,
+                                       ctx->wf_samples, P.d_status, d_stats, d_rays);
+                }
+                HIP_TRY(ctx, hipGetLastError());
+                HIP_TRY(ctx, hipMemcpyAsync(P.h_status + 4 * (group & 1), P.d_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, P.s));
+                HIP_TRY(ctx, hipEventRecord(ctx->wf_event[q][group & 1], P.s));
+                ++P.groups;
+            }
+        }
+        if (n_pipes > 1)     // the fold (and whatever the caller queues next) waits for every pipeline
+            for (int q = 0; q < n_pipes; ++q) {
+                HIP_TRY(ctx, hipEventRecord(ctx->wf_join[q], pipe[q].s));
+                HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->wf_join[q], 0));
+            }
+        WfArgs wf = pipe[0].w;
+        hipLaunchKernelGGL(wf_fold_kernel, dim3((n_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, wf, ctx->wf_samples, d_out);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (kTimers && !STATS) {   // development build: print where the waves' cycles went
@@ -274,7 +330,10 @@ void rt_destroy(rt_ctx *ctx) {
     if (ctx->wf_ctr) (void)hipFree(ctx->wf_ctr);
     if (ctx->wf_ovf) (void)hipFree(ctx->wf_ovf);
     if (ctx->wf_host_status) (void)hipHostFree(ctx->wf_host_status);
-    for (hipEvent_t ev : ctx->wf_event) if (ev) (void)hipEventDestroy(ev);
+    for (auto &evs : ctx->wf_event) for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->wf_join) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
+    for (hipStream_t st : ctx->wf_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -456,9 +515,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
         d_out = static_cast<float4 *>(tmp_out);
         if (d_rays) d_rays = static_cast<uint32_t *>(tmp_rays);
     }
-    const char *pipe = getenv("RT_PIPELINE");
-    const bool wavefront = !(pipe && strcmp(pipe, "mega") == 0);
-    if (wavefront) {
+    {
         int rc = p->collect_stats ? render_wavefront<true>(ctx, a, p, d_out, d_rays, stream) : render_wavefront<false>(ctx, a, p, d_out, d_rays, stream);
         if (rc != RT_OK) {
             (void)hipStreamSynchronize(stream);
@@ -467,39 +524,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
             return rc;
         }
     }
-    // Pixels per wave (64 >> sub_log2): fewer pixels per wave = more waves for the same image, which is
-    // what a long render of a small image needs to fill 256 CUs.  Depends on spp_count only.
-    int sub_log2 = p->spp_count >= 128 ? 3 : p->spp_count >= 8 ? 2 : p->spp_count >= 2 ? 1 : 0;
-    if (const char *e = getenv("RT_SUB_LOG2")) { int v = atoi(e); if (v >= 0 && v <= 6) sub_log2 = v; }   // tuning knobs
-    int items = 512;                                   // queue length per wave and chunk
-    if (const char *e = getenv("RT_CHUNK_ITEMS")) { int v = atoi(e); if (v >= 64 && v <= 4096) items = v; }
-    int rb = 6 - sub_log2;
-    int chunk = items >> rb;
-    if (chunk < 1) chunk = 1;
-    if (chunk > p->spp_count) chunk = p->spp_count;
-    a.sub_log2 = sub_log2;
-    a.chunk = chunk;
-    a.stack_depth = (int)ctx->stack_depth;
-    int tile_w = 2 << ((rb + 1) >> 1), tile_h = 2 << (rb >> 1);
-    int tiles_x = (x1 - x0 + tile_w - 1) / tile_w, tiles_y = (y1 - y0 + tile_h - 1) / tile_h;
-    dim3 grid((unsigned)(tiles_x * tiles_y)), block(256);
-    size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(StackEntry) + (size_t)4 * 3 * sizeof(float) * ((size_t)chunk << rb);
-    if (lds > 160 * 1024) return fail(ctx, RT_E_INVALID, "LDS budget exceeded (%zu bytes)", lds);
-    hipError_t e = hipSuccess;
-    if (lds > 64 * 1024) {   // above the default dynamic-LDS limit the kernel has to be told
-        e = p->collect_stats ? hipFuncSetAttribute((const void *)render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                             : hipFuncSetAttribute((const void *)render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(ctx, RT_E_HIP, "hipFuncSetAttribute(LDS %zu): %s", lds, hipGetErrorString(e));
-    }
-    if (wavefront) {
-        // already enqueued above
-    } else if (p->collect_stats) {
-        e = hipMemsetAsync(ctx->d_stats, 0, 64 * sizeof(unsigned long long), stream);
-        if (e == hipSuccess) hipLaunchKernelGGL(render_kernel<true>, grid, block, lds, stream, ctx->sc, a, d_out, ctx->d_stats, d_rays);
-    } else {
-        hipLaunchKernelGGL(render_kernel<false>, grid, block, lds, stream, ctx->sc, a, d_out, (unsigned long long *)nullptr, (uint32_t *)nullptr);
-    }
-    if (e == hipSuccess) e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     unsigned long long h_stats[64] = {};
     if (e == hipSuccess && p->collect_stats) {
         e = hipMemcpyAsync(h_stats, ctx->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, stream);
@@ -523,7 +548,6 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
         for (int i = 0; i < 4; ++i) stats->tex_evals[i] = h_stats[16 + i];
         stats->accepted_hits = h_stats[20];
         for (int i = 0; i < 5; ++i) { stats->phase_lanes[i] = h_stats[21 + i]; stats->phase_slots[i] = h_stats[26 + i]; }
-        for (int i = 0; i < RT_N_REGIONS; ++i) stats->region_cycles[i] = h_stats[32 + i];
     }
     return RT_OK;
 }

@@ -33,12 +33,7 @@ namespace rtk {
 #define RT_DEV __device__ __forceinline__
 #define RT_MAX_MEDIA 4
 #define RT_F32_MAX 3.40282347e+38f
-// render_kernel scheduling: traverse while at least NUM/DEN of the live lanes are walking; run a leaf
-// step once RT_LEAF_MIN lanes stand on a leaf (or nobody is on an inner node)
-#ifndef RT_TRAV_NUM
-#define RT_TRAV_NUM 1
-#define RT_TRAV_DEN 2
-#endif
+// traversal: run a leaf step once RT_LEAF_MIN lanes stand on a leaf (or nobody is on an inner node)
 #ifndef RT_LEAF_MIN
 #define RT_LEAF_MIN 16
 #endif
@@ -1026,9 +1021,6 @@ struct RenderArgs {
     float bg[3];
     uint32_t seed;
     int32_t x0, y0, x1, y1;
-    int32_t sub_log2;   // a wave owns 64 >> sub_log2 pixels (0..6)
-    int32_t chunk;      // samples per pixel per chunk (radiance slots in LDS: (64 >> sub_log2) * chunk per wave)
-    int32_t stack_depth;
     rt_camera cam;
 };
 
@@ -1069,159 +1061,6 @@ RT_DEV void phase_count(Counters &cnt, int ph, bool active) {
 RT_DEV uint32_t wave_sum(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
-}
-
-// Block = 256 lanes = 2x2 wave tiles; a wave owns P = 64 >> a.sub_log2 pixels and all of their
-// samples, taken in chunks of a.chunk samples per pixel.
-//
-// Work distribution: the P * chunk pixel samples of a chunk form a queue that the wave's 64 lanes
-// drain together — a lane that needs a path takes the next queue index (ballot + prefix count on
-// a wave-uniform counter, no atomics).  Lanes therefore stay busy until the chunk is empty however
-// uneven the path lengths are; a lane is not tied to a pixel.  Every finished path stores its
-// radiance in the wave's LDS slot of that (pixel, sample); when the chunk is done, lane l < P adds
-// pixel l's slots IN SAMPLE ORDER to its running sum — exactly the reference's fold
-// (camera.rs:195-250), independent of which lane traced what and of the tile alignment.
-//
-// Dynamic LDS per block: stack_depth * 256 * 8 B (traversal stacks) + 4 * P * chunk * 12 B (radiance slots).
-template <bool STATS>
-__global__ void __launch_bounds__(256) render_kernel(DScene sc, RenderArgs a, float4 *__restrict__ out, unsigned long long *stats,
-                                                     uint32_t *pixel_rays) {
-    extern __shared__ StackEntry lds_stack[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t wave = tid >> 6, lane = tid & 63u;
-    const uint32_t rb = 6u - (uint32_t)a.sub_log2;          // log2(P)
-    const uint32_t wx_log = (rb + 1u) >> 1, wy_log = rb >> 1;
-    const uint32_t P = 1u << rb;
-    const int tile_w = 2 << wx_log, tile_h = 2 << wy_log;
-    const int tiles_x = (a.x1 - a.x0 + tile_w - 1) / tile_w;
-    const int bx = (int)(blockIdx.x % (uint32_t)tiles_x), by = (int)(blockIdx.x / (uint32_t)tiles_x);
-    const int wave_x0 = a.x0 + bx * tile_w + (int)((wave & 1u) << wx_log);
-    const int wave_y0 = a.y0 + by * tile_h + (int)((wave >> 1) << wy_log);
-    const Stack stack{lds_stack + tid, blockDim.x, (uint32_t)a.stack_depth, nullptr, 0u};
-    const uint32_t slots = P * (uint32_t)a.chunk;            // radiance slots of this wave
-    float *rad = reinterpret_cast<float *>(lds_stack + (size_t)a.stack_depth * 256u) + (size_t)wave * 3u * slots;
-    Counters cnt{};
-    const V3 background = v3(a.bg[0], a.bg[1], a.bg[2]);
-    // lane l < P is also the keeper of pixel l's sum
-    const int own_x = wave_x0 + (int)(lane & ((1u << wx_log) - 1u)), own_y = wave_y0 + (int)((lane & (P - 1u)) >> wx_log);
-    const bool own = lane < P && own_x < a.x1 && own_y < a.y1;
-    V3 sum = v3(0.0f, 0.0f, 0.0f);
-    uint32_t paths = 0;
-    enum { ST_TRAV = 0, ST_SHADE = 1, ST_REGEN = 2, ST_DONE = 3 };
-    Path ps;
-    ps.depth = 0;
-    rts::Rng rng{0, 1};
-    Trav tv;
-    tv.ref = RT_BVH_EMPTY; tv.sp = 0; tv.best.t = 0.0f; tv.best.id = -1; tv.best.slot = 0; tv.floor_id = -1;
-    tv.inv = v3(0.0f, 0.0f, 0.0f); tv.oi = tv.inv;
-    const float T_MIN = 0.001f, T_MAX = INFINITY;   // camera.rs:264
-    const int s_end = a.spp_begin + a.spp_count;
-    for (int chunk_begin = a.spp_begin; chunk_begin < s_end; chunk_begin += a.chunk) {
-        const uint32_t c_len = (uint32_t)min(a.chunk, s_end - chunk_begin);
-        const uint32_t n_items = c_len << rb;
-        uint32_t next_q = 0;          // wave-uniform queue head
-        uint32_t q = 0;               // the item this lane is working on
-        uint32_t path_rays = 0, pixel = 0;
-        int st = ST_REGEN;
-        for (;;) {
-            const int n_trav = __popcll(__ballot(st == ST_TRAV));
-            const int n_wait = __popcll(__ballot(st == ST_SHADE || st == ST_REGEN));
-            const int alive = n_trav + n_wait;
-            if (alive == 0) break;
-            if (n_trav > 0 && (n_wait == 0 || n_trav * RT_TRAV_DEN >= alive * RT_TRAV_NUM)) {
-                int nt = n_trav;
-                do {
-                    phase_count<STATS>(cnt, PH_NODE, st == ST_TRAV && tv.ref >= 0);
-                    if (st == ST_TRAV && tv.ref >= 0) trav_node_step<STATS>(sc, T_MIN, tv, stack, cnt);
-                    const bool at_leaf = st == ST_TRAV && tv.ref < 0;
-                    const unsigned long long m_leaf = __ballot(at_leaf);
-                    const unsigned long long m_node = __ballot(st == ST_TRAV && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
-                    if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
-                        phase_count<STATS>(cnt, PH_LEAF, at_leaf);
-                        if (at_leaf) trav_leaf_step<STATS>(sc, ps.ray, T_MIN, tv, stack, cnt);
-                    }
-                    if (st == ST_TRAV && tv.ref == RT_BVH_EMPTY) {
-                        finish_trace<STATS>(sc, ps.ray, T_MIN, T_MAX, tv, cnt);
-                        st = ST_SHADE;
-                    }
-                    nt = __popcll(__ballot(st == ST_TRAV));
-                } while (nt > 0 && nt * RT_TRAV_DEN >= alive * RT_TRAV_NUM);
-            } else {
-                bool need_trace = false;
-                phase_count<STATS>(cnt, PH_SHADE, st == ST_SHADE);
-                if (st == ST_SHADE) {
-                    bool cont = shade_hit<STATS>(sc, ps, tv.best, background, rng, cnt);
-                    if (cont && ps.depth > 0) need_trace = true;             // depth <= 0 contributes 0 (camera.rs:260)
-                    else {                                                   // path over: park its radiance in its slot
-                        rad[q] = ps.radiance.x; rad[slots + q] = ps.radiance.y; rad[2u * slots + q] = ps.radiance.z;
-                        if (STATS && pixel_rays) atomicAdd(&pixel_rays[pixel], path_rays);
-                        st = ST_REGEN;
-                    }
-                }
-                // take the next queue items: lanes in ST_REGEN get consecutive indices
-                const unsigned long long m_regen = __ballot(st == ST_REGEN);
-                phase_count<STATS>(cnt, PH_START, st == ST_REGEN);
-                if (st == ST_REGEN) {
-                    q = next_q + (uint32_t)__popcll(m_regen & ((1ull << lane) - 1ull));
-                    if (q >= n_items) st = ST_DONE;
-                    else {
-                        const uint32_t pl = q & (P - 1u), k = q >> rb;       // pixel within the wave tile, sample within the chunk
-                        const int x = wave_x0 + (int)(pl & ((1u << wx_log) - 1u)), y = wave_y0 + (int)(pl >> wx_log);
-                        if (x < a.x1 && y < a.y1) {
-                            const uint32_t s = (uint32_t)chunk_begin + k;
-                            pixel = (uint32_t)y * (uint32_t)a.width + (uint32_t)x;
-                            rts::path_rng(rng, a.seed, pixel, s);
-                            ps.ray = camera_ray(sc, a, x, y, pixel, s, rng);
-                            ps.throughput = v3(1.0f, 1.0f, 1.0f);
-                            ps.radiance = v3(0.0f, 0.0f, 0.0f);
-                            ps.depth = a.max_depth;
-                            path_rays = 0;
-                            paths += 1;
-                            if (ps.depth > 0) need_trace = true;
-                            else { rad[q] = 0.0f; rad[slots + q] = 0.0f; rad[2u * slots + q] = 0.0f; }
-                        }   // an item outside the image is dropped; the lane asks again in the next phase
-                    }
-                }
-                next_q += (uint32_t)__popcll(m_regen);
-                phase_count<STATS>(cnt, PH_BEGIN, need_trace);
-                if (need_trace) {
-                    if (STATS) { cnt.rays += 1; path_rays += 1; }
-                    st = begin_trace<STATS>(sc, ps.ray, T_MIN, T_MAX, rng, tv, cnt) ? ST_TRAV : ST_SHADE;
-                }
-            }
-        }
-        // the fold of camera.rs:195-250 for this chunk: pixel `lane`, samples in order
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (own)
-            for (uint32_t k = 0; k < c_len; ++k) {
-                const uint32_t i = (k << rb) + lane;
-                sum.x += rad[i]; sum.y += rad[slots + i]; sum.z += rad[2u * slots + i];
-            }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (own) {
-        const uint32_t opix = (uint32_t)own_y * (uint32_t)a.width + (uint32_t)own_x;
-        float4 o = out[opix];
-        o.x += sum.x; o.y += sum.y; o.z += sum.z; o.w += (float)a.spp_count;
-        out[opix] = o;
-    }
-    if (STATS) {
-        uint32_t vals[31];
-        for (int i = 0; i < 5; ++i) { vals[21 + i] = cnt.phase_lanes[i]; vals[26 + i] = cnt.phase_slots[i]; }
-        vals[0] = paths;
-        vals[1] = cnt.rays; vals[2] = cnt.node_visits;
-        for (int i = 0; i < 6; ++i) vals[3 + i] = cnt.prim_tests[i];
-        vals[9] = cnt.medium_tests; vals[10] = cnt.light_pdf_evals;
-        for (int i = 0; i < 5; ++i) vals[11 + i] = cnt.shades[i];
-        for (int i = 0; i < 4; ++i) vals[16 + i] = cnt.tex_evals[i];
-        vals[20] = cnt.accepted;
-        for (int i = 0; i < 31; ++i) {
-            uint32_t w = wave_sum(vals[i]);
-            if (lane == 0 && w) atomicAdd(&stats[i], (unsigned long long)w);
-        }
-    }
 }
 
 // Parity hook: world.hit without media for caller-supplied rays (rt_trace_first_hit).

@@ -61,7 +61,8 @@ struct WfArgs {
     RenderArgs a;
     uint32_t pool;        // entries per pool buffer = RT_WF_SHARDS * cap
     uint32_t cap;         // entries per shard (multiple of 256)
-    uint32_t n_items;     // items of this batch = n_tiles * spp_batch * 64
+    uint32_t item0;       // first item of this pipeline (items are numbered over the whole batch)
+    uint32_t n_items;     // items of this pipeline in this batch (all: n_tiles * spp_batch * 64)
     uint32_t spp_batch;   // samples per pixel in this batch
     uint32_t sample0;     // absolute index of the batch's first sample
     uint32_t tiles_x, n_tiles;   // 8x8 pixel tiles over the window
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(256) wf_generate_kernel(DScene sc, WfArgs w, P
     const uint32_t off = off0 + threadIdx.x;
     const bool mine = off >= n_surv && off < n_surv + n_new;
     Counters cnt{};
-    const uint32_t g = item_head + room_before + (off - n_surv), e = j;
+    const uint32_t g = w.item0 + item_head + room_before + (off - n_surv), e = j;
     WfPath p;
     int x, y;
     const bool inside = mine && item_pixel(w, g, &x, &y, &p.sample);
