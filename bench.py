@@ -132,6 +132,14 @@ def main():
         if world == 1:
             assert np.array_equal(np.nan_to_num(img), np.nan_to_num(host_img)), "timed kernel and counting kernel disagree"
         flops = algorithmic_flops(st)
+        # HBM-side bytes per step: PMC passes of this very workload (tools/pmc.sh), committed under profiles/
+        traffic, traffic_src = None, None
+        prof = os.path.join(ROOT, "profiles", "r1", "%s_%dspp_pmc.json" % (args.workload.lower(), base_spp))
+        if world == 1 and not args.width and os.path.exists(prof):
+            with open(prof) as f:
+                ks = json.load(f)["kernels"].values()
+            traffic = sum(2.0 * (k.get("fetch_size_kb") or 0.0) + (k.get("write_size_kb") or 0.0) for k in ks) * 1024.0
+            traffic_src = os.path.relpath(prof, ROOT)
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "Mrays/sec", "value": total_rays * args.steps / elapsed / 1e6, "unit": "Mrays/s",
@@ -150,9 +158,13 @@ def main():
             "phase_wave_runs_per_ray": {n: round(s_ / 64.0 / max(st["rays"], 1) * 64, 3) for n, s_ in zip(
                 ("node_step", "leaf_step", "shade", "path_start", "begin_trace"), st["phase_slots"])},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
-                         "kernel": "rtk::render_kernel<false>", "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
-                         "note": "no dense contraction -> FP32 vector roofline (SURVEY.md §8d); flops = work counters x per-unit constants"},
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
+                         "kernel": "one rt_render call = the wavefront pipeline (rtk::wf_generate_kernel, wf_traverse_kernel, "
+                                   "wf_shade_kernel, wf_fold_kernel; wf_shade_kernel dominates on this workload)",
+                         "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
+                         "note": "no dense contraction -> FP32 vector roofline (SURVEY.md 8d); flops = work counters x per-unit constants; "
+                                 "kernel_ms = HIP events on the caller's stream around the call (the pipelines' streams fork from and join it); "
+                                 "traffic = FETCH_SIZE*2 + WRITE_SIZE bytes per step over all kernels, from " + (traffic_src or "n/a")},
         }
         if not args.no_cpu:
             sys.path.insert(0, os.path.join(ROOT, "tests"))

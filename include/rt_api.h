@@ -189,7 +189,12 @@ int rt_sampler_upload(rt_ctx *ctx, const rt_sampler_desc *sampler);
 /* Path-trace samples [spp_begin, spp_begin+spp_count) of every pixel of the tile and ADD the
  * radiance sums into out_rgba_sum (W*H*4 f32, un-normalised; alpha += spp_count).
  * Replaces the worker loop + Camera::raytrace_pixel, main.rs:1337-1361, camera.rs:186-309.
- * With out_location = RT_MEM_DEVICE the call is asynchronous on params->stream. */
+ * With out_location = RT_MEM_DEVICE the work is ordered on params->stream (it starts after what the
+ * caller queued there, and what the caller queues next sees the image); the call itself returns once
+ * the last kernels are queued, which is when the pool of in-flight paths has drained — the host
+ * feeds the pipeline, so for the host it lasts about as long as the render.  `cancel` is polled
+ * between groups of eight iterations.  The context keeps a workspace in device memory between calls
+ * (path pool 1.2 GB, sample buffer up to RT_WF_SAMPLES_MB = 8192 MB; grown on demand). */
 int rt_render(rt_ctx *ctx, const rt_render_params *params, float *out_rgba_sum, rt_stats *stats);
 
 /* Gamma / validity pass, main.rs:1363-1388:  c = clamp(sqrt(sum/spp),0,1), !is_normal(sum) -> 0,
