@@ -1,0 +1,101 @@
+"""The wavefront pipeline's own invariants (csrc/rt_wavefront.h), through the C-ABI.
+
+Every pixel sample is parked in the sample buffer and folded in sample order, and every path draws
+from its own RNG stream, so the image must be the SAME BITS whatever the pool size, the number of
+pipelines, the batch size, the LDS/HBM split of the traversal stack, the tile rectangle, or the way
+the sample range is cut into rt_render calls.  The oracle pins one of these images; the rest must
+equal it exactly.
+"""
+import contextlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def knobs(**kv):
+    """The library reads its tuning knobs from the environment on every rt_render call."""
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update({k: str(v) for k, v in kv.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def book2(rt, gpu):
+    # C3: BVH + transforms + media + textures, i.e. every kernel of the pipeline
+    scene, params, camera, sampler = rt.configs.build("C3", image_width=96, samples_per_pixel=16)
+    gpu.upload_scene(scene.flatten())
+    gpu.upload_sampler(sampler)
+    ref, _ = gpu.render(params, camera)
+    return scene, params, camera, sampler, ref
+
+
+def test_reference_image_matches_the_oracle(rt, gpu, book2):
+    scene, params, camera, sampler, ref = book2
+    want, _ = O.OracleScene(scene).render(params, camera, sampler, threads=8)
+    np.testing.assert_allclose(ref[..., :3], want[..., :3], rtol=2e-4, atol=1e-6)
+    assert np.all(ref[..., 3] == sampler.spp)
+
+
+@pytest.mark.parametrize("env", [
+    {"RT_WF_PIPES": 1},
+    {"RT_WF_POOL_LOG2": 14},                       # 16 Ki entries: the pool is refilled dozens of times
+    {"RT_WF_POOL_LOG2": 15, "RT_WF_PIPES": 1},
+    {"RT_WF_LDS_DEPTH": 3},                        # almost the whole traversal stack in the HBM overflow area
+    {"RT_WF_SAMPLES_MB": 1},                       # 64 Ki samples per batch -> several batches, several folds
+])
+def test_image_is_independent_of_the_pipeline_geometry(gpu, book2, env):
+    scene, params, camera, sampler, ref = book2
+    with knobs(**env):
+        got, _ = gpu.render(params, camera)
+    assert same_bits(got, ref), "image changed with %r" % (env,)
+
+
+def test_sample_ranges_and_tiles_compose_bit_exactly(gpu, book2):
+    scene, params, camera, sampler, ref = book2
+    W, H = params.image_width, params.image_height
+    acc = np.zeros_like(ref)
+    for b, n in ((0, 5), (5, 1), (6, 10)):         # ascending ranges into one buffer = one call
+        gpu.render(params, camera, spp_begin=b, spp_count=n, out=acc)
+    assert same_bits(acc, ref)
+    tiled = np.zeros_like(ref)
+    for tile in ((0, 0, 37, H), (37, 0, W, 41), (37, 41, W, H)):   # rectangles that are not multiples of 8
+        gpu.render(params, camera, tile=tile, out=tiled)
+    assert same_bits(tiled, ref)
+
+
+def test_counting_variant_traces_the_same_paths(gpu, book2):
+    scene, params, camera, sampler, ref = book2
+    got, st, rays = gpu.render(params, camera, stats=True, want_pixel_rays=True)
+    assert same_bits(got, ref)
+    assert st["paths"] == params.image_width * params.image_height * sampler.spp
+    assert st["rays"] == int(rays.sum()) and st["rays"] >= st["paths"]
+    assert sum(st["shades"]) == st["accepted_hits"]
+    # every node visit and leaf visit is a lane doing a phase
+    assert st["phase_lanes"][0] == st["node_visits"]
+
+
+def test_depth_zero_and_empty_ranges(rt, gpu, book2):
+    scene, params, camera, sampler, ref = book2
+    out = np.full_like(ref, 3.0)
+    gpu.render(params, camera, spp_begin=4, spp_count=0, out=out)      # nothing to do: image untouched
+    assert np.all(out == 3.0)
+    p0 = params.replace(max_ray_depth=0)                               # ray_color returns black at depth 0 (camera.rs:258-262)
+    got, _ = gpu.render(p0, camera)
+    assert np.all(got[..., :3] == 0.0) and np.all(got[..., 3] == sampler.spp)
