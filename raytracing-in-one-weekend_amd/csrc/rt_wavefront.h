@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) wf_generate_kernel(DScene sc, WfArgs w, P
 // "while-while": node steps for everyone standing on an inner node, leaf steps once enough lanes
 // stand on a leaf (RT_LEAF_MIN) or nobody is left on an inner node.
 #ifndef RT_WF_TRAV_WAVES
-#define RT_WF_TRAV_WAVES 1
+#define RT_WF_TRAV_WAVES 6      // min waves per SIMD the traverse kernel is compiled for (80 VGPRs, no spills)
 #endif
 template <bool STATS>
 __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DScene sc, PathQ q, WfCounters *ctr, uint32_t it, uint32_t cap, uint32_t lds_depth,
@@ -347,8 +347,15 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
                 if (id < 0) key = 6u;
                 else {
                     const int mat = slot < 0 ? f2i(sc.media[2 * (uint32_t)(-slot - 1) + 1].y) : f2i(sc.slots[4 * (size_t)slot + 1].y);
-                    key = (uint32_t)f2i(sc.materials[2 * mat].x) & 7u;
-                    if (key > 5u) key = 5u;
+                    // keys: 0 lambertian, solid colour  1 lambertian, checker / image  2 lambertian, Perlin noise (7 octaves:
+                    // by far the longest branch)  3 metal  4 dielectric  5 emitter, isotropic  6 miss  7 no path
+                    const float4 ma = sc.materials[2 * mat];
+                    const int mtype = f2i(ma.x);
+                    key = mtype == RTG_MAT_METAL ? 3u : mtype == RTG_MAT_DIELECTRIC ? 4u : 5u;
+                    if (mtype == RTG_MAT_LAMBERTIAN) {
+                        const int ttype = f2i(sc.textures[2 * f2i(ma.y)].x);
+                        key = ttype == RTG_TEX_SOLID ? 0u : ttype == RTG_TEX_NOISE ? 2u : 1u;
+                    }
                 }
             }
         }
