@@ -88,6 +88,7 @@ struct DScene {
     const float4 *materials;
     const float4 *textures;
     const uint32_t *perlin;
+    const uint32_t *perlin_lds;   // Perlin table 0 staged in LDS by the shade kernel (null elsewhere)
     const uint32_t *texels;
     const uint32_t *moving;
     const uint32_t *rects;
@@ -752,7 +753,7 @@ RT_DEV V3 texture_value(const DScene &sc, int tex, float u, float v, V3 p, Count
             continue;
         }
         if (type == RTG_TEX_NOISE) {  // noise_texture.rs:28-30
-            const uint32_t *tab = sc.perlin + (size_t)f2i(b.x) * RT_PERLIN_WORDS;
+            const uint32_t *tab = (sc.perlin_lds && f2i(b.x) == 0) ? sc.perlin_lds : sc.perlin + (size_t)f2i(b.x) * RT_PERLIN_WORDS;
             float k = 1.0f + pm::sinf_(b.z * p.z + 10.0f * perlin_turbulence(tab, p, 7));
             float g = 1.0f * 0.5f;
             return v3(g * k, g * k, g * k);

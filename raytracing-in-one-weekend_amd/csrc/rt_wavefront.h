@@ -315,8 +315,9 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
 #define RT_WF_SHADE_WAVES 1
 #endif
 template <bool STATS>
-__global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene sc, WfArgs w, PathQ cur, PathQ nxt, WfCounters *ctr, uint32_t it,
+__global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene sc_in, WfArgs w, PathQ cur, PathQ nxt, WfCounters *ctr, uint32_t it,
                                                        float4 *__restrict__ samples, unsigned long long *stats, uint32_t *pixel_rays) {
+    DScene sc = sc_in;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t shard = (blockIdx.x * blockDim.x) / w.cap, off0 = (blockIdx.x * blockDim.x) - shard * w.cap;   // block-uniform
     WfShard *c = &ctr[it % RT_WF_RING].sh[shard];
@@ -337,6 +338,7 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
     {
         __shared__ uint32_t s_count[8][4];
         __shared__ uint16_t s_perm[256];
+        __shared__ uint32_t s_perlin[RT_PERLIN_WORDS];
         const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
         uint32_t key = 7u;
         if (off0 + threadIdx.x < n) {
@@ -372,6 +374,12 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
             for (uint32_t v = 0; v < 4u; ++v)
                 if (k < key || (k == key && v < wv)) before += s_count[k][v];
         s_perm[before + rank] = (uint16_t)threadIdx.x;
+        // A noise texture is 7 octaves x 8 corners of dependent table look-ups (perlin.rs:84-123): blocks that
+        // hold such hits (key 2) copy the 6 KB table into LDS first (block-uniform decision).
+        if (s_count[2][0] + s_count[2][1] + s_count[2][2] + s_count[2][3] != 0u) {
+            for (uint32_t k = threadIdx.x; k < RT_PERLIN_WORDS; k += blockDim.x) s_perlin[k] = sc.perlin[k];
+            sc.perlin_lds = s_perlin;
+        }
         __syncthreads();
         i = blockIdx.x * blockDim.x + s_perm[threadIdx.x];
         if (off0 + s_perm[threadIdx.x] < n) { d = cur.ray_d[i]; flags = __float_as_uint(d.w); }
