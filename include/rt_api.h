@@ -52,7 +52,7 @@ enum rt_prim_type {
 };
 
 #define RT_SLOT_FLOATS   16   /* one primitive slot = 64 B                        */
-#define RT_NODE_FLOATS   16   /* one BVH node       = 64 B                        */
+#define RT_NODE_FLOATS   32   /* one 4-wide BVH node = 128 B                      */
 #define RT_ATTR_FLOATS   16   /* triangle shading attributes = 64 B               */
 #define RT_REC_FLOATS     8   /* material / texture / xform / medium / light rec  */
 #define RT_PERLIN_WORDS 1536  /* 256*3 f32 gradient + 3*256 i32 permutations      */
@@ -62,9 +62,10 @@ enum rt_prim_type {
 /*
  * Layouts (all little-endian 32-bit words; "i:" = int32 bit pattern in a float lane)
  *
- * BVH node  [0..5] left child box min.xyz max.xyz   [6..11] right child box
- *           [12] i: left ref  [13] i: right ref  [14..15] 0
- *           ref >= 0: inner node index;  ref < 0: leaf, ~ref = first_slot<<3 | (count-1)
+ * BVH node  4 children, boxes transposed: [0..3] min.x of child 0..3  [4..7] max.x  [8..11] min.y
+ *           [12..15] max.y  [16..19] min.z  [20..23] max.z  [24..27] i: child refs  [28..31] 0
+ *           ref >= 0: inner node index;  ref < 0: leaf, ~ref = first_slot<<3 | (count-1);
+ *           ref == RT_BVH_EMPTY: no child (its box is ignored)
  *
  * slot      [0..3]  q0 geometry   [4] i: type | flip<<4 | (xform+1)<<8
  *           (flip = FlipFace parity that survives Translate's HitRecord::new, transform.rs:36-44)

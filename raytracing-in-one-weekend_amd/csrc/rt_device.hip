@@ -352,16 +352,17 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     if (s->n_slots >= (1u << 28)) return fail(ctx, RT_E_INVALID, "too many primitives");
     if (s->bvh_stack_depth == 0 || s->bvh_stack_depth > 64) return fail(ctx, RT_E_INVALID, "bvh_stack_depth %u out of range", s->bvh_stack_depth);
     auto ref_ok = [&](int32_t ref) {
+        if (ref == RT_BVH_EMPTY) return true;   // a 4-wide node may have fewer than four children
         if (ref >= 0) return (uint32_t)ref < s->n_bvh_nodes;
         uint32_t code = (uint32_t)~ref;
         return (uint64_t)(code >> 3) + (code & 7u) + 1u <= s->n_slots;
     };
     if (s->bvh_root_ref != RT_BVH_EMPTY && !ref_ok(s->bvh_root_ref)) return fail(ctx, RT_E_INVALID, "bvh_root_ref out of range");
     for (uint32_t i = 0; i < s->n_bvh_nodes; ++i) {
-        int32_t l, r;
-        memcpy(&l, &s->bvh_nodes[i * RT_NODE_FLOATS + 12], 4);
-        memcpy(&r, &s->bvh_nodes[i * RT_NODE_FLOATS + 13], 4);
-        if (!ref_ok(l) || !ref_ok(r)) return fail(ctx, RT_E_INVALID, "bvh node %u has a child out of range", i);
+        int32_t refs[4];
+        memcpy(refs, &s->bvh_nodes[(size_t)i * RT_NODE_FLOATS + 24], 16);
+        for (int32_t r : refs)
+            if (!ref_ok(r)) return fail(ctx, RT_E_INVALID, "bvh node %u has a child out of range", i);
     }
     bool tris = false;
     for (uint32_t i = 0; i < s->n_slots; ++i) {

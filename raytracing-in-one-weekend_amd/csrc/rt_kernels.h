@@ -396,6 +396,40 @@ RT_DEV int32_t pop_ref(const Stack &st, uint32_t &sp) {
     return (int32_t)(sp < st.lds_depth ? st.lds[sp * st.stride] : st.ovf[(size_t)(sp - st.lds_depth) * st.ovf_stride]);
 }
 
+// One visit of a 4-wide node (rt_api.h layout): all four child boxes are tested against [t_min, best_t], the
+// nearest hit child is returned, the other hit children are pushed farthest first (so the nearer one is popped
+// first); with no hit the next stack entry is returned.  The order only decides how soon best_t shrinks: the
+// closest hit and its tie-break do not depend on it.
+RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t_min, float best_t, const Stack &stack, uint32_t &sp) {
+    const float4 *n = sc.nodes + 8 * (size_t)ref;
+    const float4 lx = n[0], hx = n[1], ly = n[2], hy = n[3], lz = n[4], hz = n[5], rf = n[6];
+    const float lo_x[4] = {lx.x, lx.y, lx.z, lx.w}, hi_x[4] = {hx.x, hx.y, hx.z, hx.w};
+    const float lo_y[4] = {ly.x, ly.y, ly.z, ly.w}, hi_y[4] = {hy.x, hy.y, hy.z, hy.w};
+    const float lo_z[4] = {lz.x, lz.y, lz.z, lz.w}, hi_z[4] = {hz.x, hz.y, hz.z, hz.w};
+    const int32_t refs[4] = {f2i(rf.x), f2i(rf.y), f2i(rf.z), f2i(rf.w)};
+    // sort key: entry distance with the child index in its two lowest bits (distances are >= t_min > 0 in the
+    // renderer, so their bit patterns order like unsigned integers); a miss sorts last
+    uint32_t key[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float tn;
+        const bool hit = slab(v3(lo_x[c], lo_y[c], lo_z[c]), v3(hi_x[c], hi_y[c], hi_z[c]), inv, oi, t_min, best_t, &tn) && refs[c] != RT_BVH_EMPTY;
+        key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xffffffffu;
+    }
+#define RT_CSWAP(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
+    RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+    if (key[0] == 0xffffffffu) return pop_ref(stack, sp);
+#pragma unroll
+    for (int j = 3; j >= 1; --j)
+        if (key[j] != 0xffffffffu) {
+            const uint32_t c = key[j] & 3u;
+            stack_push(stack, sp, c == 0u ? refs[0] : c == 1u ? refs[1] : c == 2u ? refs[2] : refs[3]);
+        }
+    const uint32_t c0 = key[0] & 3u;
+    return c0 == 0u ? refs[0] : c0 == 1u ? refs[1] : c0 == 2u ? refs[2] : refs[3];
+}
+
 // "while-while" traversal: every lane walks inner nodes until it stands on a leaf (or is done);
 // only then does the wave run the primitive tests, so node steps and leaf steps are not
 // serialised against each other inside one iteration.
@@ -413,24 +447,8 @@ RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_
     uint32_t sp = 0;
     for (;;) {
         while (ref >= 0 && ref != RT_BVH_EMPTY) {
-            const float4 *n = sc.nodes + 4 * (size_t)ref;
-            float4 a = n[0], b = n[1], c = n[2], d = n[3];
             if (STATS) cnt.node_visits += 1;
-            float tl, tr;
-            bool hl = slab(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), inv, oi, t_min, best.t, &tl);
-            bool hr = slab(v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), inv, oi, t_min, best.t, &tr);
-            int32_t rl = f2i(d.x), rr = f2i(d.y);
-            if (hl && hr) {
-                bool left_first = tl <= tr;
-                stack_push(stack, sp, left_first ? rr : rl);
-                ref = left_first ? rl : rr;
-            } else if (hl) {
-                ref = rl;
-            } else if (hr) {
-                ref = rr;
-            } else {
-                ref = pop_ref(stack, sp);
-            }
+            ref = node4_visit(sc, ref, inv, oi, t_min, best.t, stack, sp);
         }
         if (ref == RT_BVH_EMPTY) return;
         uint32_t code = (uint32_t)~ref;
@@ -641,24 +659,8 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
 
 template <bool STATS>
 RT_DEV void trav_node_step(const DScene &sc, float t_min, Trav &tv, const Stack &stack, Counters &cnt) {
-    const float4 *n = sc.nodes + 4 * (size_t)tv.ref;
-    float4 a = n[0], b = n[1], c = n[2], d = n[3];
     if (STATS) cnt.node_visits += 1;
-    float tl, tr;
-    bool hl = slab(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), tv.inv, tv.oi, t_min, tv.best.t, &tl);
-    bool hr = slab(v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), tv.inv, tv.oi, t_min, tv.best.t, &tr);
-    int32_t rl = f2i(d.x), rr = f2i(d.y);
-    if (hl && hr) {
-        bool left_first = tl <= tr;
-        stack_push(stack, tv.sp, left_first ? rr : rl);
-        tv.ref = left_first ? rl : rr;
-    } else if (hl) {
-        tv.ref = rl;
-    } else if (hr) {
-        tv.ref = rr;
-    } else {
-        tv.ref = pop_ref(stack, tv.sp);
-    }
+    tv.ref = node4_visit(sc, tv.ref, tv.inv, tv.oi, t_min, tv.best.t, stack, tv.sp);
 }
 
 template <bool STATS>

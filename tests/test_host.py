@@ -155,12 +155,14 @@ def check_bvh(flat):
                 seen[s] += 1
             return
         n = nodes[ref]
-        refs = n[12:14].view(np.int32)
-        for c in range(2):
-            walk(int(refs[c]), depth + 1)
+        refs = n[24:28].view(np.int32)
+        assert (refs != 0x7FFFFFFF).sum() >= 2                     # a node has 2..4 children
+        for c in range(4):
+            if refs[c] != 0x7FFFFFFF:                              # RT_BVH_EMPTY: no child
+                walk(int(refs[c]), depth + 1)
     walk(d.bvh_root_ref, 0)
     assert (seen == 1).all(), "every slot must sit in exactly one leaf"
-    assert max_depth[0] + 1 <= d.bvh_stack_depth
+    assert 3 * max_depth[0] + 1 <= d.bvh_stack_depth             # a visit pushes at most three children
     ids = slots[:, 6].view(np.int32)
     assert len(set(ids.tolist())) == d.n_slots
 
