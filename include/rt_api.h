@@ -132,6 +132,9 @@ typedef struct rt_camera {
 
 enum rt_mem_location { RT_MEM_HOST = 0, RT_MEM_DEVICE = 1 };
 
+/* Projection (main.rs:1140-1146); the numbering of the RON config's enum */
+enum rt_projection { RT_PROJ_PERSPECTIVE = 0, RT_PROJ_ORTHOGRAPHIC = 1, RT_PROJ_FISHEYE = 2, RT_PROJ_SPHERICAL_PANORAMIC = 3 };
+
 typedef struct rt_render_params {
     uint32_t  struct_size;
     int32_t   image_width, image_height;     /* full frame (main.rs:1160-1161)                 */
@@ -148,6 +151,8 @@ typedef struct rt_render_params {
     int32_t   collect_stats;                 /* 1 = run the counting variant and fill rt_stats */
     uint32_t *pixel_rays;                    /* optional W*H counters (same location as the image): += rays
                                                 traced for that pixel; only with collect_stats = 1 */
+    int32_t   projection;                    /* rt_projection (camera.rs:198-249)              */
+    float     psi_max, lambda_max;           /* radians (main.rs:1199-1200); FishEye / SphericalPanoramic */
 } rt_render_params;
 
 /* Work counters (SURVEY.md §8(d) FLOP model inputs).  Only filled when collect_stats=1. */

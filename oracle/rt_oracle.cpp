@@ -1013,7 +1013,15 @@ Color ray_color(const Ray &r, Color background, const HittableList &world, const
     if (depth <= 0) return C(0, 0, 0);
     ++tl_rays;
     HitRecord rec;
-    if (!world.hit(r, 0.001f, INFINITY, &rec)) return background;
+    static const bool trace = getenv("ORC_TRACE") != nullptr;   // debugging aid: one line per bounce on stderr
+    if (!world.hit(r, 0.001f, INFINITY, &rec)) {
+        if (trace) fprintf(stderr, "[orc] depth %d ray %.9g %.9g %.9g | %.9g %.9g %.9g | %.9g miss\n", depth, r.origin.x, r.origin.y, r.origin.z,
+                           r.direction.x, r.direction.y, r.direction.z, r.time);
+        return background;
+    }
+    if (trace) fprintf(stderr, "[orc] depth %d ray %.9g %.9g %.9g | %.9g %.9g %.9g | %.9g hit prim %u t %.9g front %d n %.9g %.9g %.9g\n", depth,
+                       r.origin.x, r.origin.y, r.origin.z, r.direction.x, r.direction.y, r.direction.z, r.time, rec.prim_id, rec.t,
+                       (int)rec.front_face, rec.normal.x, rec.normal.y, rec.normal.z);
     Color emitted = rec.mtl->emitted(r, rec, rec.u, rec.v, rec.p);
     ScatterRecord scatter;
     if (!rec.mtl->scatter(r, rec, &scatter)) return emitted;
@@ -1029,34 +1037,75 @@ Color ray_color(const Ray &r, Color background, const HittableList &world, const
 
 struct Vec2 { Real x, y; };
 
-// camera.rs:186-251 for one pixel, samples [spp_begin, spp_begin + spp_count), Perspective only
-Color raytrace_pixel(int x, int y, const orc_render_params &p, const rt_sampler_desc &smp, const HittableList &world,
-                     const Hittable *lights) {
+// The four get_ray_* of camera.rs:82-184 for a point (u, v) of the view plane and a unit-disk lens sample.
+bool project(const orc_render_params &p, Real u, Real v, Vec2 disk, Ray &r) {
     const rt_camera &cam = p.camera;
     Vec3 origin = V(cam.origin[0], cam.origin[1], cam.origin[2]);
     Vec3 llc = V(cam.lower_left_corner[0], cam.lower_left_corner[1], cam.lower_left_corner[2]);
     Vec3 horizontal = V(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
     Vec3 vertical = V(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
-    Vec3 cu = V(cam.u[0], cam.u[1], cam.u[2]), cv = V(cam.v[0], cam.v[1], cam.v[2]);
+    Vec3 cu = V(cam.u[0], cam.u[1], cam.u[2]), cv = V(cam.v[0], cam.v[1], cam.v[2]), cw = V(cam.w[0], cam.w[1], cam.w[2]);
+    if (p.projection == RT_PROJ_PERSPECTIVE || p.projection == RT_PROJ_ORTHOGRAPHIC) {
+        Vec2 rd{cam.lens_radius * disk.x, cam.lens_radius * disk.y};
+        Vec3 offset = cu * rd.x + cv * rd.y;
+        if (p.projection == RT_PROJ_PERSPECTIVE) {  // camera.rs:82-96
+            r.origin = origin + offset;
+            r.direction = llc + u * horizontal + v * vertical - origin - offset;
+        } else {                                    // camera.rs:98-112
+            r.origin = llc + u * horizontal + v * vertical + offset;
+            r.direction = -cw;
+        }
+        return true;
+    }
+    Vec2 pn{2.0f * u - 1.0f, 2.0f * v - 1.0f};
+    r.origin = origin;
+    if (p.projection == RT_PROJ_FISHEYE) {          // camera.rs:114-148
+        Real rsqr = pn.x * pn.x + pn.y * pn.y;
+        if (!(rsqr <= 1.0f)) return false;
+        Real rr = std::sqrt(rsqr);
+        Real psi = rr * p.psi_max;
+        Real sin_psi, cos_psi;
+        m_sincos(psi, &sin_psi, &cos_psi);
+        Real cos_alpha = pn.x / rr, sin_alpha = pn.y / rr;
+        r.direction = (sin_psi * cos_alpha) * cu + (sin_psi * sin_alpha) * cv - cos_psi * cw;
+    } else {                                        // camera.rs:150-184
+        Real lambda = pn.x * p.lambda_max, psi = pn.y * p.psi_max;
+        Real phi = 3.14159265358979323846f - lambda;
+        Real theta = 0.5f * 3.14159265358979323846f - psi;
+        Real sin_theta, cos_theta, sin_phi, cos_phi;
+        m_sincos(theta, &sin_theta, &cos_theta);
+        m_sincos(phi, &sin_phi, &cos_phi);
+        r.direction = (sin_theta * sin_phi) * cu + cos_theta * cv + (sin_theta * cos_phi) * cw;
+    }
+    return true;
+}
+
+// camera.rs:186-251 for one pixel, samples [spp_begin, spp_begin + spp_count)
+Color raytrace_pixel(int x, int y, const orc_render_params &p, const rt_sampler_desc &smp, const HittableList &world,
+                     const Hittable *lights) {
+    Vec3 origin = V(p.camera.origin[0], p.camera.origin[1], p.camera.origin[2]);
     Color background = C(p.background[0], p.background[1], p.background[2]);
     uint32_t pixel = (uint32_t)y * (uint32_t)p.image_width + (uint32_t)x;
+    // Perspective / Orthographic draw a lens sample too: the square and disk look-ups share the sampler's counter
+    // (sampling.rs:137-163), so a sample takes slots 2s and 2s+1; the other projections take slot s.
+    const bool lens = p.projection == RT_PROJ_PERSPECTIVE || p.projection == RT_PROJ_ORTHOGRAPHIC;
     Color color = C(0, 0, 0);
     for (int s = p.spp_begin; s < p.spp_begin + p.spp_count; ++s) {
         rts::Rng rng;
         rts::path_rng(rng, p.seed, pixel, (uint32_t)s);
         tl_rng = &rng;
-        uint32_t i0 = rts::sampler_index(p.seed, pixel, 2u * (uint32_t)s, smp.sets, smp.samples_in_set, smp.shuffled_indices);
+        uint32_t i0 = rts::sampler_index(p.seed, pixel, lens ? 2u * (uint32_t)s : (uint32_t)s, smp.sets, smp.samples_in_set, smp.shuffled_indices);
         Vec2 off{smp.samples[2 * i0], smp.samples[2 * i0 + 1]};  // camera.rs:196
         Real u = ((Real)x + off.x) / (Real)(p.image_width - 1);
         Real v = 1.0f - ((Real)y + off.y) / (Real)(p.image_height - 1);
-        // camera.rs:82-96
-        uint32_t i1 = rts::sampler_index(p.seed, pixel, 2u * (uint32_t)s + 1u, smp.sets, smp.samples_in_set, smp.shuffled_indices);
-        Vec2 rd{cam.lens_radius * smp.disk_samples[2 * i1], cam.lens_radius * smp.disk_samples[2 * i1 + 1]};
-        Vec3 offset = cu * rd.x + cv * rd.y;
-        Vec3 ro = origin + offset;
-        Vec3 rdir = llc + u * horizontal + v * vertical - origin - offset;
-        Real time = random_real();
-        Ray r{ro, rdir, time};
+        Vec2 disk{0.0f, 0.0f};
+        if (lens) {
+            uint32_t i1 = rts::sampler_index(p.seed, pixel, 2u * (uint32_t)s + 1u, smp.sets, smp.samples_in_set, smp.shuffled_indices);
+            disk = Vec2{smp.disk_samples[2 * i1], smp.disk_samples[2 * i1 + 1]};
+        }
+        Ray r{origin, origin, 0.0f};
+        if (!project(p, u, v, disk, r)) continue;   // FishEye None: the colour is unchanged and no time is drawn
+        r.time = random_real();
         color = color + ray_color(r, background, world, lights, p.max_ray_depth);
     }
     tl_rng = nullptr;
@@ -1068,6 +1117,15 @@ Color raytrace_pixel(int x, int y, const orc_render_params &p, const rt_sampler_
 extern "C" {
 
 const char *orc_last_error(void) { return g_error.c_str(); }
+
+// KAT hook: the ray of get_ray_<projection>(u, v) with lens sample (dx, dy); out6 = origin, direction; 0 = None
+int orc_project(const orc_render_params *p, float u, float v, float dx, float dy, float *out6) {
+    Ray r{V(0, 0, 0), V(0, 0, 0), 0.0f};
+    if (!project(*p, u, v, Vec2{dx, dy}, r)) return 0;
+    out6[0] = r.origin.x; out6[1] = r.origin.y; out6[2] = r.origin.z;
+    out6[3] = r.direction.x; out6[4] = r.direction.y; out6[5] = r.direction.z;
+    return 1;
+}
 
 int orc_scene_create(const rtg_graph *g, const orc_options *opt, orc_scene **out) {
     if (!g || !out) { set_error("null argument"); return RT_E_INVALID; }

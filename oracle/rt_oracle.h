@@ -43,10 +43,16 @@ typedef struct orc_render_params {
     rt_camera camera;
     int32_t   threads;              /* worker threads (main.rs:1326); tiles of block_pixels^2 in a LIFO queue */
     int32_t   block_pixels;
+    int32_t   projection;           /* rt_projection */
+    float     psi_max, lambda_max;  /* radians */
 } orc_render_params;
 
 /* Adds radiance sums into out_rgba_sum (W*H*4, alpha += spp_count) like rt_render.
  * rays_out (may be NULL) = closest-hit queries issued by ray_color; pixel_rays (may be NULL) = per pixel. */
+/* KAT hook: the ray of get_ray_<projection>(u, v) (camera.rs:82-184) with unit-disk lens sample (dx, dy);
+ * out6 = origin, direction.  Returns 0 for FishEye's None. */
+int orc_project(const orc_render_params *p, float u, float v, float dx, float dy, float *out6);
+
 int orc_render(const orc_scene *s, const orc_render_params *p, const rt_sampler_desc *sampler, float *out_rgba_sum,
                uint64_t *rays_out, uint32_t *pixel_rays);
 

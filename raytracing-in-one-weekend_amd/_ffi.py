@@ -75,6 +75,7 @@ class rt_render_params(C.Structure):
         ("cancel", C.POINTER(C.c_int32)),
         ("collect_stats", C.c_int32),
         ("pixel_rays", c_u32_p),
+        ("projection", C.c_int32), ("psi_max", C.c_float), ("lambda_max", C.c_float),
     ]
 
 

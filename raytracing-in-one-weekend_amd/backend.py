@@ -56,6 +56,7 @@ class HipBackend:
         p.seed = seed
         p.tile_x0, p.tile_y0, p.tile_x1, p.tile_y1 = tile if tile else (0, 0, W, H)
         p.camera = camera
+        p.projection, p.psi_max, p.lambda_max = params.projection, params.psi_max_radians, params.lambda_max_radians
         return p, W, H
 
     def render(self, params, camera, seed=0x5EED, spp_begin=0, spp_count=None, tile=None, width=None, height=None,

@@ -479,6 +479,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
     if (p->samples_per_pixel != (int32_t)ctx->sc.spp) return fail(ctx, RT_E_INVALID, "samples_per_pixel %d does not match the sampler table (%u)", p->samples_per_pixel, ctx->sc.spp);
     if (p->spp_begin < 0 || p->spp_count < 0 || p->spp_begin + p->spp_count > p->samples_per_pixel) return fail(ctx, RT_E_INVALID, "sample range outside [0, spp)");
     if (p->collect_stats && !stats) return fail(ctx, RT_E_INVALID, "collect_stats without a stats struct");
+    if (p->projection < RT_PROJ_PERSPECTIVE || p->projection > RT_PROJ_SPHERICAL_PANORAMIC) return fail(ctx, RT_E_INVALID, "unknown projection %d", p->projection);
     int x0 = p->tile_x0 < 0 ? 0 : p->tile_x0, y0 = p->tile_y0 < 0 ? 0 : p->tile_y0;
     int x1 = p->tile_x1 > p->image_width ? p->image_width : p->tile_x1, y1 = p->tile_y1 > p->image_height ? p->image_height : p->tile_y1;
     if (p->cancel && *p->cancel) return fail(ctx, RT_E_CANCELLED, "cancelled");
@@ -494,6 +495,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
     a.seed = p->seed;
     a.x0 = x0; a.y0 = y0; a.x1 = x1; a.y1 = y1;
     a.cam = p->camera;
+    a.projection = p->projection; a.psi_max = p->psi_max; a.lambda_max = p->lambda_max;
 
     const bool host_out = p->out_location == RT_MEM_HOST;
     hipStream_t stream = host_out ? ctx->stream : (p->stream ? (hipStream_t)p->stream : nullptr);

@@ -1031,29 +1031,65 @@ struct RenderArgs {
     float bg[3];
     uint32_t seed;
     int32_t x0, y0, x1, y1;
+    int32_t projection;
+    float psi_max, lambda_max;
     rt_camera cam;
 };
 
 // camera.rs:196-198 + 82-96
-RT_DEV Ray camera_ray(const DScene &sc, const RenderArgs &a, int x, int y, uint32_t pixel, uint32_t s, rts::Rng &rng) {
-    uint32_t i0 = rts::sampler_index(a.seed, pixel, 2u * s, sc.sets, sc.spp, sc.shuffled);
+// One camera ray (camera.rs:196-249).  Perspective and Orthographic take a lens sample, so a pixel sample uses
+// sampler slots 2s and 2s+1 (the reference's square and disk look-ups share one counter, sampling.rs:137-163);
+// FishEye and SphericalPanoramic take none and use slot s.  FishEye returns false outside the unit disk: the
+// sample then adds nothing and draws no ray time (camera.rs:221-233).
+RT_DEV bool camera_ray(const DScene &sc, const RenderArgs &a, int x, int y, uint32_t pixel, uint32_t s, rts::Rng &rng, Ray *out) {
+    const bool lens = a.projection == RT_PROJ_PERSPECTIVE || a.projection == RT_PROJ_ORTHOGRAPHIC;
+    uint32_t i0 = rts::sampler_index(a.seed, pixel, lens ? 2u * s : s, sc.sets, sc.spp, sc.shuffled);
     float2 off = sc.samples[i0];
     float u = ((float)x + off.x) / (float)(a.width - 1);
     float v = 1.0f - ((float)y + off.y) / (float)(a.height - 1);
-    uint32_t i1 = rts::sampler_index(a.seed, pixel, 2u * s + 1u, sc.sets, sc.spp, sc.shuffled);
-    float2 dk = sc.disk[i1];
-    float rdx = a.cam.lens_radius * dk.x, rdy = a.cam.lens_radius * dk.y;
-    V3 cu = v3(a.cam.u[0], a.cam.u[1], a.cam.u[2]), cv = v3(a.cam.v[0], a.cam.v[1], a.cam.v[2]);
+    V3 cu = v3(a.cam.u[0], a.cam.u[1], a.cam.u[2]), cv = v3(a.cam.v[0], a.cam.v[1], a.cam.v[2]), cw = v3(a.cam.w[0], a.cam.w[1], a.cam.w[2]);
     V3 origin = v3(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
-    V3 llc = v3(a.cam.lower_left_corner[0], a.cam.lower_left_corner[1], a.cam.lower_left_corner[2]);
-    V3 hor = v3(a.cam.horizontal[0], a.cam.horizontal[1], a.cam.horizontal[2]);
-    V3 ver = v3(a.cam.vertical[0], a.cam.vertical[1], a.cam.vertical[2]);
-    V3 offset = cu * rdx + cv * rdy;
     Ray r;
-    r.o = origin + offset;
-    r.d = llc + u * hor + v * ver - origin - offset;
+    if (lens) {
+        uint32_t i1 = rts::sampler_index(a.seed, pixel, 2u * s + 1u, sc.sets, sc.spp, sc.shuffled);
+        float2 dk = sc.disk[i1];
+        float rdx = a.cam.lens_radius * dk.x, rdy = a.cam.lens_radius * dk.y;
+        V3 llc = v3(a.cam.lower_left_corner[0], a.cam.lower_left_corner[1], a.cam.lower_left_corner[2]);
+        V3 hor = v3(a.cam.horizontal[0], a.cam.horizontal[1], a.cam.horizontal[2]);
+        V3 ver = v3(a.cam.vertical[0], a.cam.vertical[1], a.cam.vertical[2]);
+        V3 offset = cu * rdx + cv * rdy;
+        if (a.projection == RT_PROJ_PERSPECTIVE) {          // camera.rs:82-96
+            r.o = origin + offset;
+            r.d = llc + u * hor + v * ver - origin - offset;
+        } else {                                            // camera.rs:98-112
+            r.o = llc + u * hor + v * ver + offset;
+            r.d = -cw;
+        }
+    } else {
+        float pnx = 2.0f * u - 1.0f, pny = 2.0f * v - 1.0f;
+        r.o = origin;
+        if (a.projection == RT_PROJ_FISHEYE) {              // camera.rs:114-148
+            float rsqr = pnx * pnx + pny * pny;
+            if (!(rsqr <= 1.0f)) return false;
+            float rr = sqrtf(rsqr);
+            float psi = rr * a.psi_max;
+            float sin_psi, cos_psi;
+            pm::sincosf_(psi, &sin_psi, &cos_psi);
+            float cos_alpha = pnx / rr, sin_alpha = pny / rr;
+            r.d = (sin_psi * cos_alpha) * cu + (sin_psi * sin_alpha) * cv - cos_psi * cw;
+        } else {                                            // camera.rs:150-184
+            float lambda = pnx * a.lambda_max, psi = pny * a.psi_max;
+            float phi = 3.14159265358979323846f - lambda;
+            float theta = 0.5f * 3.14159265358979323846f - psi;
+            float sin_theta, cos_theta, sin_phi, cos_phi;
+            pm::sincosf_(theta, &sin_theta, &cos_theta);
+            pm::sincosf_(phi, &sin_phi, &cos_phi);
+            r.d = (sin_theta * sin_phi) * cu + cos_theta * cv + (sin_theta * cos_phi) * cw;
+        }
+    }
     r.time = rts::random_real(rng);
-    return r;
+    *out = r;
+    return true;
 }
 
 // Lane-occupancy telemetry; call where the wave is converged.

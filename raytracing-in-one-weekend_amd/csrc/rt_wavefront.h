@@ -190,12 +190,19 @@ __global__ void __launch_bounds__(256) wf_generate_kernel(DScene sc, WfArgs w, P
         nxt.ray_d[e] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
     }
     phase_count<STATS>(cnt, PH_START, start);
+    bool have_ray = false;
     if (start) {
         p.pixel = (uint32_t)y * (uint32_t)w.a.width + (uint32_t)x;
         rts::path_rng(p.rng, w.a.seed, p.pixel, p.sample);
         RG_BEGIN(RG_CAMERA);
-        p.ps.ray = camera_ray(sc, w.a, x, y, p.pixel, p.sample, p.rng);
+        have_ray = camera_ray(sc, w.a, x, y, p.pixel, p.sample, p.rng, &p.ps.ray);
         RG_END(RG_CAMERA);
+        if (!have_ray) {       // FishEye outside its disk: the sample adds nothing (camera.rs:231-233)
+            samples[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            nxt.ray_d[e] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+        }
+    }
+    if (have_ray) {
         p.ps.throughput = v3(1.0f, 1.0f, 1.0f);
         p.ps.radiance = v3(0.0f, 0.0f, 0.0f);
         p.ps.depth = w.a.max_depth;

@@ -39,6 +39,10 @@ class RaytracerParams:
             setattr(self, name, list(v) if hasattr(v, "__len__") else v)
         self.image_height = _ffi.host_lib().rth_image_height(C.byref(user))
         self.projection_name = PROJECTIONS[user.projection]
+        # main.rs:1199-1200: f32::to_radians = x * (PI_f32 / 180_f32), one f32 multiply
+        k = np.float32(np.float32(np.pi) / np.float32(180.0))
+        self.psi_max_radians = float(np.float32(user.psi_max) * k)
+        self.lambda_max_radians = float(np.float32(user.lambda_max) * k)
 
     def replace(self, **kw):
         u = _ffi.rth_user_config()

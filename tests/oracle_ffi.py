@@ -23,7 +23,8 @@ class orc_render_params(C.Structure):
                 ("spp_begin", C.c_int32), ("spp_count", C.c_int32), ("max_ray_depth", C.c_int32),
                 ("background", C.c_float * 3), ("seed", C.c_uint32),
                 ("tile_x0", C.c_int32), ("tile_y0", C.c_int32), ("tile_x1", C.c_int32), ("tile_y1", C.c_int32),
-                ("camera", ffi.rt_camera), ("threads", C.c_int32), ("block_pixels", C.c_int32)]
+                ("camera", ffi.rt_camera), ("threads", C.c_int32), ("block_pixels", C.c_int32),
+                ("projection", C.c_int32), ("psi_max", C.c_float), ("lambda_max", C.c_float)]
 
 
 def lib():
@@ -79,6 +80,7 @@ class OracleScene:
         p.camera = camera
         p.threads = threads
         p.block_pixels = params.worker_block_pixels
+        p.projection, p.psi_max, p.lambda_max = params.projection, params.psi_max_radians, params.lambda_max_radians
         out = np.zeros((H, W, 4), np.float32)
         rays = C.c_uint64(0)
         pr = np.zeros((H, W), np.uint32) if want_pixel_rays else None

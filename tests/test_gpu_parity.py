@@ -142,3 +142,24 @@ def test_degenerate_rays_follow_the_reference_fold(rt, gpu):
     c = O.OracleScene(scene).first_hit(r)
     assert np.array_equal(g[0], c[0]) and np.array_equal(g[1], c[1]) and np.array_equal(g[3], c[3])
     assert (g[0] != 0xFFFFFFFF).mean() > 0.2
+
+
+@pytest.mark.parametrize("projection,name", [(1, "Orthographic"), (2, "FishEye"), (3, "SphericalPanoramic")])
+def test_other_projections_match_the_oracle(rt, gpu, projection, name):
+    """camera.rs:98-184: same paths as the oracle (equal per-pixel ray counts), sums within 2e-4."""
+    scene, params, camera, sampler = rt.configs.build("C1", image_width=96, samples_per_pixel=4)
+    # look_from raised so that the Orthographic view plane stays above the ground sphere: ray origins INSIDE the
+    # r=1000 sphere make paths of 1000-unit segments, whose f32 sphere tests accept far-away small spheres by
+    # cancellation (DESIGN.md section 3, tests/test_oracle_kat.py::test_cancellation_false_positive) -- hits a BVH culls
+    params = params.replace(projection=projection, psi_max=150.0, lambda_max=170.0, look_from=(13.0, 4.0, 3.0))
+    assert params.projection_name == name
+    camera = params.camera()
+    gpu.upload_scene(scene.flatten())
+    gpu.upload_sampler(sampler)
+    got, st, rays = gpu.render(params, camera, stats=True, want_pixel_rays=True)
+    want, n_rays, want_rays = O.OracleScene(scene).render(params, camera, sampler, want_pixel_rays=True)
+    assert np.array_equal(rays, want_rays) and st["rays"] == n_rays
+    np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=2e-4, atol=1e-6)
+    assert np.all(got[..., 3] == sampler.spp)
+    if projection == 2:      # FishEye: the corners of the frame are outside the unit disk and trace nothing
+        assert rays[0, 0] == 0 and rays[-1, -1] == 0 and rays[rays.shape[0] // 2, rays.shape[1] // 2] > 0

@@ -197,3 +197,69 @@ def test_mesh_first_hit_vs_nearest_modes():
     assert pid[0] == 0 and t[0] == 5.0
     pid, t, *_ = O.OracleScene(sc, mesh_nearest=True).first_hit(r)
     assert pid[0] == 1 and t[0] == 2.0
+
+
+def test_camera_projections_follow_camera_rs():
+    """get_ray_perspective / _ortho / _fisheye / _spherical_panoramic (camera.rs:82-184), recomputed in float64."""
+    import ctypes as C
+    lib = O.lib()
+    lib.orc_project.argtypes = [C.POINTER(O.orc_render_params), C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    lib.orc_project.restype = C.c_int
+    scene, params, camera, sampler = rt.configs.build("C1", image_width=64, samples_per_pixel=4)
+    cam = {k: np.array(list(getattr(camera, k)), np.float64) for k in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w")}
+    lens = float(camera.lens_radius)
+    psi_max, lam_max = np.radians(120.0), np.radians(170.0)
+
+    def expected(proj, u, v, dx, dy):
+        if proj in (0, 1):
+            off = cam["u"] * (lens * dx) + cam["v"] * (lens * dy)
+            point = cam["lower_left_corner"] + u * cam["horizontal"] + v * cam["vertical"]
+            return (cam["origin"] + off, point - cam["origin"] - off) if proj == 0 else (point + off, -cam["w"])
+        px, py = 2 * u - 1, 2 * v - 1
+        if proj == 2:
+            r2 = px * px + py * py
+            if r2 > 1:
+                return None
+            r = np.sqrt(r2)
+            psi = r * psi_max
+            return cam["origin"], np.sin(psi) * (px / r) * cam["u"] + np.sin(psi) * (py / r) * cam["v"] - np.cos(psi) * cam["w"]
+        phi, theta = np.pi - px * lam_max, 0.5 * np.pi - py * psi_max
+        return cam["origin"], np.sin(theta) * np.sin(phi) * cam["u"] + np.cos(theta) * cam["v"] + np.sin(theta) * np.cos(phi) * cam["w"]
+
+    rng = np.random.default_rng(3)
+    p = O.orc_render_params()
+    p.camera = camera
+    p.psi_max, p.lambda_max = psi_max, lam_max
+    none_seen = 0
+    for proj in range(4):
+        p.projection = proj
+        for _ in range(200):
+            u, v, dx, dy = (float(np.float32(x)) for x in (rng.random(), rng.random(), rng.uniform(-0.7, 0.7), rng.uniform(-0.7, 0.7)))
+            out = (C.c_float * 6)()
+            ok = lib.orc_project(C.byref(p), u, v, dx, dy, out)
+            want = expected(proj, u, v, dx, dy)
+            if want is None:
+                assert ok == 0
+                none_seen += 1
+                continue
+            assert ok == 1
+            np.testing.assert_allclose(np.array(out[:3]), want[0], rtol=2e-6, atol=2e-6)
+            np.testing.assert_allclose(np.array(out[3:]), want[1], rtol=1e-5, atol=2e-6 * np.abs(want[1]).max())
+    assert none_seen > 10          # FishEye corners lie outside the unit disk: Option::None (camera.rs:146)
+
+
+def test_cancellation_false_positive():
+    """A documented deviation class.  sphere.rs:46-66 in f32 accepts this ray for a r=0.2
+    sphere it passes 0.66 away from: origin and direction are ~2000 long (a path segment INSIDE the r=1000 ground
+    sphere), half_b^2 - a*c cancels, and the reported hit point is not on the sphere.  The reference's flat list
+    takes the hit; any traversal that culls by bounding box (the GPU's) does not.  Found with an Orthographic view
+    of RandomWorld whose view plane dips into the ground; C1-C4 as configured have no such rays."""
+    scene, params, camera, sampler = rt.configs.build("C1", image_width=96, samples_per_pixel=4)
+    ray = np.array([[-647.327393, -1432.85925, -627.37561, 909.112427, 1986.85925, 878.007812, 0.662694097]], np.float32).T.copy()
+    pid, t, *_ = O.OracleScene(scene).first_hit(ray)
+    slots = scene.flatten().slots()
+    s = slots[slots[:, 6].view(np.int32) == int(pid[0])][0]
+    centre, radius = s[0:3].astype(np.float64), float(s[3])
+    assert radius == pytest.approx(0.2)
+    p = ray[0:3, 0].astype(np.float64) + float(t[0]) * ray[3:6, 0].astype(np.float64)
+    assert np.linalg.norm(p - centre) > 3 * radius          # the "hit point" is nowhere near the sphere
