@@ -52,7 +52,7 @@ enum rt_prim_type {
 };
 
 #define RT_SLOT_FLOATS   16   /* one primitive slot = 64 B                        */
-#define RT_NODE_FLOATS   32   /* one 4-wide BVH node = 128 B                      */
+#define RT_NODE_FLOATS   16   /* one 4-wide BVH node = 64 B                       */
 #define RT_ATTR_FLOATS   16   /* triangle shading attributes = 64 B               */
 #define RT_REC_FLOATS     8   /* material / texture / xform / medium / light rec  */
 #define RT_PERLIN_WORDS 1536  /* 256*3 f32 gradient + 3*256 i32 permutations      */
@@ -62,8 +62,11 @@ enum rt_prim_type {
 /*
  * Layouts (all little-endian 32-bit words; "i:" = int32 bit pattern in a float lane)
  *
- * BVH node  4 children, boxes transposed: [0..3] min.x of child 0..3  [4..7] max.x  [8..11] min.y
- *           [12..15] max.y  [16..19] min.z  [20..23] max.z  [24..27] i: child refs  [28..31] 0
+ * BVH node  4 children, their boxes quantised to 8 bits on the grid of the node's own box:
+ *           [0..2] origin  [3..5] scale  (plane = origin + scale * q, q = 0..255; child boxes are rounded
+ *           OUTWARDS, so the quantised box contains the child's)
+ *           [6] u32: min.x q of children 0..3 (child c in byte c)  [7] max.x  [8] min.y  [9] max.y
+ *           [10] min.z  [11] max.z  [12..15] i: child refs
  *           ref >= 0: inner node index;  ref < 0: leaf, ~ref = first_slot<<3 | (count-1);
  *           ref == RT_BVH_EMPTY: no child (its box is ignored)
  *

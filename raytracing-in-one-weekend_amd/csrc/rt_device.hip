@@ -360,7 +360,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     if (s->bvh_root_ref != RT_BVH_EMPTY && !ref_ok(s->bvh_root_ref)) return fail(ctx, RT_E_INVALID, "bvh_root_ref out of range");
     for (uint32_t i = 0; i < s->n_bvh_nodes; ++i) {
         int32_t refs[4];
-        memcpy(refs, &s->bvh_nodes[(size_t)i * RT_NODE_FLOATS + 24], 16);
+        memcpy(refs, &s->bvh_nodes[(size_t)i * RT_NODE_FLOATS + 12], 16);
         for (int32_t r : refs)
             if (!ref_ok(r)) return fail(ctx, RT_E_INVALID, "bvh node %u has a child out of range", i);
     }

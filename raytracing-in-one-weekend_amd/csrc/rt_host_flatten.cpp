@@ -8,6 +8,7 @@
 // hittable_list.rs:39-50) by primitive id.  Layouts: include/rt_api.h.
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <functional>
 #include <numeric>
 
@@ -513,13 +514,43 @@ int rth_flatten(const rtg_graph *g, rth_flat **out_flat) {
             }
             const size_t me = flat->nodes.size() / RT_NODE_FLOATS;
             flat->nodes.resize((me + 1) * RT_NODE_FLOATS, 0.0f);
+            // Child boxes on the 8-bit grid of the node's box (a visit then fetches 64 instead of 128 bytes: the
+            // walk's scattered node fetches keep the texture path busier than its arithmetic keeps the SIMDs).
+            // Rounded outwards and checked in exact arithmetic, so culling stays conservative.
+            Box parent;
+            parent.reset();
+            for (const Child &k : ch) parent.add(k.box);
+            float origin[3], scale[3];
+            uint32_t q[6] = {0, 0, 0, 0, 0, 0};   // lo.x hi.x lo.y hi.y lo.z hi.z, child c in byte c
+            for (int a = 0; a < 3; ++a) {
+                origin[a] = parent.lo[a];
+                scale[a] = (parent.hi[a] - parent.lo[a]) / 255.0f;
+                while ((double)origin[a] + (double)scale[a] * 255.0 < (double)parent.hi[a]) scale[a] = std::nextafter(scale[a], FLT_MAX);
+                for (size_t c = 0; c < ch.size(); ++c) {
+                    int ql = 0, qh = 255;
+                    if (scale[a] > 0.0f) {
+                        ql = (int)std::floor(((double)ch[c].box.lo[a] - (double)origin[a]) / (double)scale[a]);
+                        qh = (int)std::ceil(((double)ch[c].box.hi[a] - (double)origin[a]) / (double)scale[a]);
+                        ql = std::min(255, std::max(0, ql));
+                        qh = std::min(255, std::max(0, qh));
+                        while (ql > 0 && (double)origin[a] + (double)scale[a] * ql > (double)ch[c].box.lo[a]) --ql;
+                        while (qh < 255 && (double)origin[a] + (double)scale[a] * qh < (double)ch[c].box.hi[a]) ++qh;
+                    } else {
+                        ql = qh = 0;   // flat node box along this axis: every child plane is the origin
+                    }
+                    q[2 * a] |= (uint32_t)ql << (8 * c);
+                    q[2 * a + 1] |= (uint32_t)qh << (8 * c);
+                }
+            }
+            {
+                float *d = &flat->nodes[me * RT_NODE_FLOATS];
+                for (int a = 0; a < 3; ++a) { d[a] = origin[a]; d[3 + a] = scale[a]; }
+                for (int k = 0; k < 6; ++k) memcpy(d + 6 + k, &q[k], 4);
+            }
             for (size_t c = 0; c < 4; ++c) {
                 int32_t ref = RT_BVH_EMPTY;
                 if (c < ch.size()) ref = ch[c].ref >= 0 ? collapse(ch[c].ref, depth + 1) : leaf_ref(ch[c].ref);
-                float *d = &flat->nodes[me * RT_NODE_FLOATS];   // (re-fetched: the recursion grows the vector)
-                if (c < ch.size())
-                    for (int a = 0; a < 3; ++a) { d[8 * a + c] = ch[c].box.lo[a]; d[8 * a + 4 + c] = ch[c].box.hi[a]; }
-                d[24 + c] = i2f(ref);
+                flat->nodes[me * RT_NODE_FLOATS + 12 + c] = i2f(ref);   // (indexed afresh: the recursion grows the vector)
             }
             return (int32_t)me;
         };

@@ -396,24 +396,31 @@ RT_DEV int32_t pop_ref(const Stack &st, uint32_t &sp) {
     return (int32_t)(sp < st.lds_depth ? st.lds[sp * st.stride] : st.ovf[(size_t)(sp - st.lds_depth) * st.ovf_stride]);
 }
 
-// One visit of a 4-wide node (rt_api.h layout): all four child boxes are tested against [t_min, best_t], the
+// One visit of a 4-wide node (rt_api.h layout, 64 bytes): all four child boxes are tested against [t_min, best_t], the
 // nearest hit child is returned, the other hit children are pushed farthest first (so the nearer one is popped
 // first); with no hit the next stack entry is returned.  The order only decides how soon best_t shrinks: the
 // closest hit and its tie-break do not depend on it.
 RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t_min, float best_t, const Stack &stack, uint32_t &sp) {
-    const float4 *n = sc.nodes + 8 * (size_t)ref;
-    const float4 lx = n[0], hx = n[1], ly = n[2], hy = n[3], lz = n[4], hz = n[5], rf = n[6];
-    const float lo_x[4] = {lx.x, lx.y, lx.z, lx.w}, hi_x[4] = {hx.x, hx.y, hx.z, hx.w};
-    const float lo_y[4] = {ly.x, ly.y, ly.z, ly.w}, hi_y[4] = {hy.x, hy.y, hy.z, hy.w};
-    const float lo_z[4] = {lz.x, lz.y, lz.z, lz.w}, hi_z[4] = {hz.x, hz.y, hz.z, hz.w};
+    const float4 *n = sc.nodes + 4 * (size_t)ref;
+    const float4 n0 = n[0], n1 = n[1], n2 = n[2], rf = n[3];
+    // plane = origin + scale * q, so its ray parameter (plane - o) * inv is q * (scale * inv) + (origin * inv - o * inv)
+    const float sx = n0.w * inv.x, sy = n1.x * inv.y, sz = n1.y * inv.z;
+    const float ox = __builtin_fmaf(n0.x, inv.x, -oi.x), oy = __builtin_fmaf(n0.y, inv.y, -oi.y), oz = __builtin_fmaf(n0.z, inv.z, -oi.z);
+    const uint32_t qlx = __float_as_uint(n1.z), qhx = __float_as_uint(n1.w), qly = __float_as_uint(n2.x), qhy = __float_as_uint(n2.y),
+                   qlz = __float_as_uint(n2.z), qhz = __float_as_uint(n2.w);
     const int32_t refs[4] = {f2i(rf.x), f2i(rf.y), f2i(rf.z), f2i(rf.w)};
     // sort key: entry distance with the child index in its two lowest bits (distances are >= t_min > 0 in the
     // renderer, so their bit patterns order like unsigned integers); a miss sorts last
     uint32_t key[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        float tn;
-        const bool hit = slab(v3(lo_x[c], lo_y[c], lo_z[c]), v3(hi_x[c], hi_y[c], hi_z[c]), inv, oi, t_min, best_t, &tn) && refs[c] != RT_BVH_EMPTY;
+        const int sh = 8 * c;
+        const float tx0 = __builtin_fmaf((float)((qlx >> sh) & 255u), sx, ox), tx1 = __builtin_fmaf((float)((qhx >> sh) & 255u), sx, ox);
+        const float ty0 = __builtin_fmaf((float)((qly >> sh) & 255u), sy, oy), ty1 = __builtin_fmaf((float)((qhy >> sh) & 255u), sy, oy);
+        const float tz0 = __builtin_fmaf((float)((qlz >> sh) & 255u), sz, oz), tz1 = __builtin_fmaf((float)((qhz >> sh) & 255u), sz, oz);
+        const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
+        const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), best_t));
+        const bool hit = tn <= tf * 1.0000004f && refs[c] != RT_BVH_EMPTY;
         key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xffffffffu;
     }
 #define RT_CSWAP(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }

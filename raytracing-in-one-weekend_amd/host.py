@@ -191,7 +191,7 @@ class FlatScene:
         return np.ctypeslib.as_array(self.desc.slots, (self.desc.n_slots, 16)).copy() if self.desc.n_slots else np.zeros((0, 16), np.float32)
 
     def nodes(self):
-        return np.ctypeslib.as_array(self.desc.bvh_nodes, (self.desc.n_bvh_nodes, 32)).copy() if self.desc.n_bvh_nodes else np.zeros((0, 32), np.float32)
+        return np.ctypeslib.as_array(self.desc.bvh_nodes, (self.desc.n_bvh_nodes, 16)).copy() if self.desc.n_bvh_nodes else np.zeros((0, 16), np.float32)
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -139,7 +139,7 @@ def test_scene_builders_object_counts(rt):
         rt.host.Scene.build("Blocks")
 
 
-def check_bvh(flat):
+def check_bvh(flat, expect_boxes=False):
     nodes, slots, d = flat.nodes(), flat.slots(), flat.desc
     seen = np.zeros(d.n_slots, np.int32)
     max_depth = [0]
@@ -148,19 +148,57 @@ def check_bvh(flat):
         code = ~ref & 0xFFFFFFFF
         return range(code >> 3, (code >> 3) + (code & 7) + 1)
 
+    def slot_box(s):
+        """World box of a sphere / moving-sphere slot without transform (enough for RandomWorld); None otherwise."""
+        w4 = int(slots[s, 4].view(np.int32))
+        kind, xf = w4 & 15, (w4 >> 8) - 1
+        if xf >= 0 or kind > 1:
+            return None
+        c0, r = slots[s, 0:3].astype(np.float64), float(slots[s, 3])
+        lo, hi = c0 - r, c0 + r
+        if kind == 1:
+            c1 = slots[s, 8:11].astype(np.float64)
+            lo, hi = np.minimum(lo, c1 - r), np.maximum(hi, c1 + r)
+        return lo, hi
+
+    def child_box(n, c):
+        """The quantised child box of include/rt_api.h, decoded in exact arithmetic."""
+        origin, scale = n[0:3].astype(np.float64), n[3:6].astype(np.float64)
+        q = n[6:12].view(np.uint32)
+        lo = np.array([origin[a] + scale[a] * ((int(q[2 * a]) >> (8 * c)) & 255) for a in range(3)])
+        hi = np.array([origin[a] + scale[a] * ((int(q[2 * a + 1]) >> (8 * c)) & 255) for a in range(3)])
+        return lo, hi
+
     def walk(ref, depth):
+        """Returns the exact box of everything below `ref` (None if it holds a primitive this test cannot box)."""
         max_depth[0] = max(max_depth[0], depth)
         if ref < 0:
+            boxes = []
             for s in leaf_slots(ref):
                 seen[s] += 1
-            return
+                boxes.append(slot_box(s))
+            if any(b is None for b in boxes):
+                return None
+            return np.min([b[0] for b in boxes], 0), np.max([b[1] for b in boxes], 0)
         n = nodes[ref]
-        refs = n[24:28].view(np.int32)
+        refs = n[12:16].view(np.int32)
         assert (refs != 0x7FFFFFFF).sum() >= 2                     # a node has 2..4 children
+        below = []
         for c in range(4):
             if refs[c] != 0x7FFFFFFF:                              # RT_BVH_EMPTY: no child
-                walk(int(refs[c]), depth + 1)
+                sub = walk(int(refs[c]), depth + 1)
+                below.append(sub)
+                if sub is not None:                                # conservative: the 8-bit box contains what it culls for
+                    lo, hi = child_box(n, c)
+                    assert (lo <= sub[0]).all() and (hi >= sub[1]).all(), "quantised child box cuts into its subtree"
+                    checked[0] += 1
+        if any(b is None for b in below):
+            return None
+        return np.min([b[0] for b in below], 0), np.max([b[1] for b in below], 0)
+    checked = [0]
     walk(d.bvh_root_ref, 0)
+    if expect_boxes:
+        assert checked[0] > 100
     assert (seen == 1).all(), "every slot must sit in exactly one leaf"
     assert 3 * max_depth[0] + 1 <= d.bvh_stack_depth             # a visit pushes at most three children
     ids = slots[:, 6].view(np.int32)
@@ -169,7 +207,7 @@ def check_bvh(flat):
 
 def test_flatten_bvh_invariants(rt):
     f = rt.host.Scene.build("RandomWorld").flatten()
-    check_bvh(f)
+    check_bvh(f, expect_boxes=True)
     f = rt.host.Scene.build("Chapter2Final", assets=rt.host.Assets(need=("earthmap",))).flatten()
     check_bvh(f)
     slots = f.slots()
