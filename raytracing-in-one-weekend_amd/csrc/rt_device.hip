@@ -430,7 +430,26 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     UP(xforms, s->xforms, (size_t)s->n_xforms * RT_REC_FLOATS * 4);
     UP(media, s->media, (size_t)s->n_media * RT_REC_FLOATS * 4);
     UP(lights, s->lights, (size_t)s->n_lights * RT_REC_FLOATS * 4);
-    UP(materials, s->materials, (size_t)s->n_materials * RT_REC_FLOATS * 4);
+    {   // device copy of the materials: word 7 = kind of the material's texture + 1 (0 = untextured), and a solid
+        // colour is copied into words 2..4, so that most bounces need no texture fetch (rt_kernels.h material_texture)
+        std::vector<float> dev_mats(s->materials, s->materials + (size_t)s->n_materials * RT_REC_FLOATS);
+        for (uint32_t i = 0; i < s->n_materials; ++i) {
+            float *m = &dev_mats[(size_t)i * RT_REC_FLOATS];
+            int32_t type, tex, kind_plus_1 = 0;
+            memcpy(&type, m, 4);
+            memcpy(&tex, m + 1, 4);
+            if (type == RTG_MAT_LAMBERTIAN || type == RTG_MAT_DIFFUSE_LIGHT || type == RTG_MAT_ISOTROPIC) {
+                const float *t = &s->textures[(size_t)tex * RT_REC_FLOATS];
+                int32_t kind;
+                memcpy(&kind, t, 4);
+                kind_plus_1 = kind + 1;
+                if (kind == RTG_TEX_SOLID) memcpy(m + 2, t + 1, 12);
+            }
+            memcpy(m + 7, &kind_plus_1, 4);
+        }
+        UP(materials, dev_mats.data(), dev_mats.size() * 4);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // dev_mats goes out of scope
+    }
     UP(textures, s->textures, (size_t)s->n_textures * RT_REC_FLOATS * 4);
     UP(perlin, s->perlin, (size_t)s->n_perlin * RT_PERLIN_WORDS * 4);
     UP(texels, s->texels, (size_t)s->n_texel_bytes);

@@ -899,6 +899,18 @@ RT_DEV float schlick(float cosine, float ior) {  // types.rs:165-169
 
 /* ------------------------------------------------------------------ one bounce of ray_color */
 
+// Texture of a material.  Word 7 of the DEVICE copy of a material record (rt_scene_upload) holds the kind of
+// its texture + 1, and for a solid colour words 2..4 hold that colour: most bounces then need no texture fetch
+// (one link less in the slot -> material -> texture chain of dependent loads).
+template <bool STATS>
+RT_DEV V3 material_texture(const DScene &sc, float4 ma, float4 mb, float u, float v, V3 p, Counters &cnt) {
+    if (f2i(mb.w) == RTG_TEX_SOLID + 1) {
+        if (STATS) cnt.tex_evals[RTG_TEX_SOLID] += 1;
+        return v3(ma.z, ma.w, mb.x);
+    }
+    return texture_value<STATS>(sc, f2i(ma.y), u, v, p, cnt);
+}
+
 struct Path {
     Ray ray;
     V3 throughput;   // product of the weights so far
@@ -935,9 +947,8 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
     } else {
         int mat = f2i(sc.slots[4 * (size_t)best.slot + 1].y);
         float4 ma = sc.materials[2 * mat];
-        int mtype = f2i(ma.x);
-        bool want_uv = (mtype == RTG_MAT_LAMBERTIAN || mtype == RTG_MAT_DIFFUSE_LIGHT || mtype == RTG_MAT_ISOTROPIC) &&
-                       texture_needs_uv(sc, f2i(ma.y));
+        int tkind = f2i(sc.materials[2 * mat + 1].w);   // 0 untextured, kind + 1 otherwise
+        bool want_uv = tkind > RTG_TEX_SOLID + 1 && texture_needs_uv(sc, f2i(ma.y));
         RG_BEGIN(RG_RECORD);
         rec = slot_record(sc, (uint32_t)best.slot, ps.ray, best.t, want_uv);
         RG_END(RG_RECORD);
@@ -950,7 +961,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
     case RTG_MAT_DIFFUSE_LIGHT: {  // diffuse_light.rs:43-56; scatter = None -> return emitted
         RG_BEGIN(RG_EMIT);
         if (rec.front_face) {
-            V3 e = texture_value<STATS>(sc, f2i(ma.y), rec.u, rec.v, rec.p, cnt);
+            V3 e = material_texture<STATS>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
             ps.radiance = ps.radiance + ps.throughput * e;
         }
         RG_END(RG_EMIT);
@@ -989,7 +1000,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
     case RTG_MAT_ISOTROPIC: {  // isotropic.rs:26-35
         RG_BEGIN(RG_ISO);
         V3 dir = random_in_unit_sphere(rng);
-        V3 att = texture_value<STATS>(sc, f2i(ma.y), rec.u, rec.v, rec.p, cnt);
+        V3 att = material_texture<STATS>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
         ps.throughput = ps.throughput * att;
         ps.ray = Ray{rec.p, dir, rec.t};  // sic: time = hit t
         RG_END(RG_ISO);
@@ -998,7 +1009,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
     default: {  // Lambertian: lambertian.rs:33-51 + camera.rs:271-301
         RG_BEGIN(RG_LAMBERT);
         RG_BEGIN(RG_TEXTURE);
-        V3 albedo = texture_value<STATS>(sc, f2i(ma.y), rec.u, rec.v, rec.p, cnt);
+        V3 albedo = material_texture<STATS>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
         RG_END(RG_TEXTURE);
         Onb uvw = onb_from(rec.normal);
         V3 dir;

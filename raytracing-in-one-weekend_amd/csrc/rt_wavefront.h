@@ -358,13 +358,9 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
                     const int mat = slot < 0 ? f2i(sc.media[2 * (uint32_t)(-slot - 1) + 1].y) : f2i(sc.slots[4 * (size_t)slot + 1].y);
                     // keys: 0 lambertian, solid colour  1 lambertian, checker / image  2 lambertian, Perlin noise (7 octaves:
                     // by far the longest branch)  3 metal  4 dielectric  5 emitter, isotropic  6 miss  7 no path
-                    const float4 ma = sc.materials[2 * mat];
-                    const int mtype = f2i(ma.x);
+                    const int mtype = f2i(sc.materials[2 * mat].x), tkind = f2i(sc.materials[2 * mat + 1].w) - 1;   // rt_kernels.h material_texture()
                     key = mtype == RTG_MAT_METAL ? 3u : mtype == RTG_MAT_DIELECTRIC ? 4u : 5u;
-                    if (mtype == RTG_MAT_LAMBERTIAN) {
-                        const int ttype = f2i(sc.textures[2 * f2i(ma.y)].x);
-                        key = ttype == RTG_TEX_SOLID ? 0u : ttype == RTG_TEX_NOISE ? 2u : 1u;
-                    }
+                    if (mtype == RTG_MAT_LAMBERTIAN) key = tkind == RTG_TEX_SOLID ? 0u : tkind == RTG_TEX_NOISE ? 2u : 1u;
                 }
             }
         }
