@@ -48,13 +48,19 @@ enum rt_prim_type {
     RT_PRIM_XY_RECT       = 2,
     RT_PRIM_XZ_RECT       = 3,
     RT_PRIM_YZ_RECT       = 4,
-    RT_PRIM_TRIANGLE      = 5
+    RT_PRIM_TRIANGLE      = 5,
+    RT_PRIM_CYLINDER      = 6,   /* the quadrics are tested for every ray (always-list), never through the BVH: */
+    RT_PRIM_CONE          = 7,   /* cone / paraboloid / hyperboloid ignore t_min (cone.rs:61-65), so a box test  */
+    RT_PRIM_PARABOLOID    = 8,   /* over [t_min, t_max] could cull a hit the reference accepts                  */
+    RT_PRIM_HYPERBOLOID   = 9
 };
+#define RT_N_PRIM_TYPES 10
 
 #define RT_SLOT_FLOATS   16   /* one primitive slot = 64 B                        */
 #define RT_NODE_FLOATS   16   /* one 4-wide BVH node = 64 B                       */
 #define RT_ATTR_FLOATS   16   /* triangle shading attributes = 64 B               */
 #define RT_REC_FLOATS     8   /* material / texture / xform / medium / light rec  */
+#define RT_MATRIX_FLOATS 36   /* one general Transform: three 3x4 matrices        */
 #define RT_PERLIN_WORDS 1536  /* 256*3 f32 gradient + 3*256 i32 permutations      */
 #define RT_BVH_EMPTY  0x7fffffff
 #define RT_MISS       0xffffffffu
@@ -78,9 +84,17 @@ enum rt_prim_type {
  *   moving sphere  q0 = c0x c0y c0z r   [7] = time0   q2 = c1x c1y c1z time1
  *   rects          q0 = a0 a1 b0 b1     [7] = k         (XY: a=x b=y, XZ: a=x b=z, YZ: a=y b=z)
  *   triangle       q0 = p1x p1y p1z p2x [7] = p3z  q2 = p2y p2z p3x p3y
+ *   cylinder       q0 = radius zmin zmax phi_max           (cylinder.rs:12-19)
+ *   cone           q0 = radius height 0 phi_max            (cone.rs:12-17)
+ *   paraboloid     q0 = radius zmin zmax phi_max           (paraboloid.rs:10-16)
+ *   hyperboloid    q0 = p1x p1y p1z phi_max  [7] = zmin  q2 = p2x p2y p2z zmax  [12] ah [13] ch
+ *                  (p1, p2 after the constructor's swap, hyperboloid.rs:34)
  * tri attr  n1.xyz n2.xyz n3.xyz uv1.xy uv2.xy uv3.xy 0        (indexed by slot)
  * xform     [0] i: bit0 rotate-y, bit1 translate  [1] sin [2] cos [3..5] offset
- *           meaning Translate(RotateY(obj)) (transform.rs:9-153)
+ *           meaning Translate(RotateY(obj)) (transform.rs:9-153);
+ *           bit2 = general Transform (transform.rs:155-213), then [1] i: index into `matrices`
+ * matrix    [0..11] world2object rows 0..2 (a00 a01 a02 a03 | a10 ..)  [12..23] obj2world  [24..35] normal2world
+ *           (= adjoint(world2object) transposed, transform.rs:171); last rows are 0,0,0,1 and not stored
  * medium    [0..3] boundary sphere c,r  [4] neg_inv_density  [5] i: material  [6] i: prim id
  * light     [0] i: rt_prim_type (sphere or rect)  [1..5] q0 (+k for rects);  type 255 = an object that
  *           keeps the trait defaults of hittable.rs:47-53 (pdf_value 0, random = unit_x)
@@ -111,6 +125,7 @@ typedef struct rt_scene_desc {
                                        hit test can ACCEPT a NaN distance for a finite ray (0/0 when the ray lies in the
                                        plane, rectangles.rs:23-34); scanned when a direction component is exactly 0 */
     uint32_t       n_prims;         /* number of primitive ids in the scene */
+    const float   *matrices;        uint32_t n_matrices;     /* RT_MATRIX_FLOATS each; slots under one are in the always-list */
 } rt_scene_desc;
 
 /* Sampler table: SamplerBase<MultiJittered> (raytracer/src/sampling.rs:11-24, 137-163). */
@@ -164,7 +179,7 @@ typedef struct rt_stats {
     uint64_t rays;             /* closest-hit queries issued by ray_color (camera.rs:264) */
     uint64_t node_visits;      /* BVH nodes fetched                                     */
     uint64_t box_tests;        /* child boxes tested (2 per node visit)                 */
-    uint64_t prim_tests[6];    /* by rt_prim_type, traversal + always-list              */
+    uint64_t prim_tests[RT_N_PRIM_TYPES]; /* by rt_prim_type, traversal + always-list   */
     uint64_t medium_tests;     /* ConstantMedium::hit evaluations                       */
     uint64_t light_pdf_evals;  /* lights.pdf_value object evaluations                   */
     uint64_t shades[5];        /* scatter calls by rtg_material_type                    */

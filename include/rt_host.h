@@ -7,6 +7,7 @@
  *   MultiJitteredSampler::new                              raytracer/src/sampling.rs:30-135, 233-253
  *   scene_random_world / scene_cornell_box /
  *   scene_final_chapter2 / scene_mesh                      raytracer/src/main.rs:106-199, 362-522, 685-828, 969-1029
+ *   scene_geometric_primitives / scene_blocks              raytracer/src/main.rs:830-967, 1031-1133
  *   ImportedGeometry (GLB) + TriangleMesh::new             raytracer/src/geometry_import.rs:306-507, triangle_mesh.rs:43-119
  *   "Hittable::flatten" (does not exist in the reference)  object tree -> flat arrays + BVH of include/rt_api.h
  *
@@ -62,6 +63,15 @@ int rth_add_constant_medium(rth_scene *s, int boundary, int albedo_tex, float de
 int rth_add_triangle_mesh(rth_scene *s, const rtg_vertex *verts, uint32_t n_verts, const uint32_t *indices,
                           uint32_t n_indices, const rtg_mesh_node *nodes, uint32_t n_nodes,
                           const float obj2world[16], int mtl);
+/* Transform::new (transform.rs:162-175): obj2world row-major 4x4 whose last row must be 0,0,0,1 (every Transform
+ * the reference builds is affine); RT_E_INVALID when it cannot be inverted (the reference asserts, mat4.rs:610). */
+int rth_add_transform(rth_scene *s, int child, const float obj2world[16]);
+/* Quadrics in their own frame, axis = z: Cylinder::new (cylinder.rs:32-44), Cone::new (cone.rs:20-27),
+ * Paraboloid::new (paraboloid.rs:23-37), Hyperboloid::new (hyperboloid.rs:26-67).  phi_max in radians. */
+int rth_add_cylinder(rth_scene *s, float radius, float z0, float z1, float phi_max, int mtl);
+int rth_add_cone(rth_scene *s, float radius, float height, float phi_max, int mtl);
+int rth_add_paraboloid(rth_scene *s, float radius, float zmin, float zmax, float phi_max, int mtl);
+int rth_add_hyperboloid(rth_scene *s, const float p1[3], const float p2[3], float phi_max, int mtl);
 int rth_set_roots(rth_scene *s, int world_list, int lights_list);
 
 /* ------------------------------------------------------------------ glTF import */
@@ -83,10 +93,13 @@ typedef struct rth_scene_assets {
     rth_image uvgrid09;          /* data/textures/uv_grids/ash_uvgrid09.jpg (MeshTest teapot) */
     const rth_geometry *teapot;  /* data/models/teapot/teapot.glb        (MeshTest) */
     int32_t mesh_grid;           /* MeshTest: K -> K x K baked copies of the mesh (1 = the reference scene) */
+    rth_image uvgrid03;          /* data/textures/uv_grids/ash_uvgrid03.jpg (GeometricPrimitives) */
+    rth_image uvgrid08;          /* data/textures/uv_grids/ash_uvgrid08.jpg (GeometricPrimitives) */
+    rth_image uvgrid10;          /* data/textures/uv_grids/ash_uvgrid10.jpg (GeometricPrimitives) */
 } rth_scene_assets;
 
 /* name = a `Scene` variant of main.rs:93-104: "RandomWorld", "CornellBox", "Chapter2Final",
- * "MeshTest".  seed feeds every random_* call of the builder (the reference is unseeded). */
+ * "MeshTest", "GeometricPrimitives", "Blocks".  seed feeds every random_* call of the builder (the reference is unseeded). */
 int rth_build_scene(rth_scene *s, const char *name, uint32_t seed, const rth_scene_assets *assets);
 
 /* ------------------------------------------------------------------ config (RON) */

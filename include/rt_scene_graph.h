@@ -16,8 +16,8 @@
  * world root, children in stored order:  Sphere/MovingSphere/rect = 1 id,
  * Block = 6 ids in the side order of raytracer/src/block.rs:27-79,
  * ConstantMedium = 1 id (its boundary is not numbered), TriangleMesh = one id per
- * triangle in index order.  Wrappers (FlipFace, Translate, RotateY, Bvh, List)
- * take no id.  Host flattener and oracle must both follow this rule.
+ * triangle in index order, a quadric = 1 id.  Wrappers (FlipFace, Translate, RotateY,
+ * Transform, Bvh, List) take no id.  Host flattener and oracle must both follow this rule.
  */
 #ifndef RT_SCENE_GRAPH_H
 #define RT_SCENE_GRAPH_H
@@ -42,7 +42,13 @@ enum rtg_node_type {
     RTG_BVH             = 9,  /* bvh.rs:15-89               children = the slice handed to BvhNode::new */
     RTG_LIST            = 10, /* hittable_list.rs:7-76      children in insertion order            */
     RTG_CONSTANT_MEDIUM = 11, /* constant_medium.rs:13-95   f = density, 1 child (boundary); material = Isotropic */
-    RTG_TRIANGLE_MESH   = 12  /* triangle_mesh.rs:15-268    i[0] = mesh index                      */
+    RTG_TRIANGLE_MESH   = 12, /* triangle_mesh.rs:15-268    i[0] = mesh index                      */
+    RTG_TRANSFORM       = 13, /* transform.rs:155-213       f = rows 0..2 of obj2world (row-major 3x4; the last row
+                                                            is 0,0,0,1: every Transform of main.rs is affine), 1 child */
+    RTG_CYLINDER        = 14, /* cylinder.rs:12-162         f = radius, zmin, zmax, phi_max        */
+    RTG_CONE            = 15, /* cone.rs:12-129             f = radius, height, phi_max            */
+    RTG_PARABOLOID      = 16, /* paraboloid.rs:10-145       f = radius, zmin, zmax, phi_max        */
+    RTG_HYPERBOLOID     = 17  /* hyperboloid.rs:13-170      f = p1 xyz, p2 xyz (the constructor's arguments), phi_max */
 };
 
 typedef struct rtg_node {

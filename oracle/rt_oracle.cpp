@@ -692,6 +692,306 @@ struct RotateY : Hittable {  // :57-153
     Vec3 random(Vec3 v) const override { return obj->random(v); }
 };
 
+/* ------------------------------------------------------------------ math/src/mat4.rs (what Transform uses) */
+struct Mat4 {  // row-major a[r*4+c], mat4.rs:20-41
+    Real a[16];
+    Real at(int r, int c) const { return a[r * 4 + c]; }
+    Real &at(int r, int c) { return a[r * 4 + c]; }
+};
+#define A(r, c) m.at(r, c)
+inline Real mat4_det(const Mat4 &m) {  // mat4.rs:536-561, the two index typos in l2 and l4 kept
+    Real k1 = A(0, 0) * A(1, 1) - A(0, 1) * A(1, 0), l1 = A(2, 2) * A(3, 3) - A(2, 3) * A(3, 2);
+    Real k2 = A(0, 0) * A(1, 2) - A(0, 2) * A(1, 0), l2 = A(2, 1) * A(3, 3) - A(1, 2) * A(3, 1);
+    Real k3 = A(0, 0) * A(1, 3) - A(0, 3) * A(1, 0), l3 = A(2, 1) * A(3, 2) - A(2, 2) * A(3, 1);
+    Real k4 = A(0, 1) * A(1, 2) - A(0, 2) * A(1, 1), l4 = A(2, 0) * A(3, 3) - A(3, 2) * A(3, 0);
+    Real k5 = A(0, 1) * A(1, 3) - A(0, 3) * A(1, 1), l5 = A(2, 0) * A(3, 2) - A(2, 2) * A(3, 0);
+    Real k6 = A(0, 2) * A(1, 3) - A(0, 3) * A(1, 2), l6 = A(2, 0) * A(3, 1) - A(2, 1) * A(3, 0);
+    return k1 * l1 - k2 * l2 + k3 * l3 + k4 * l4 - k5 * l5 + k6 * l6;
+}
+inline Mat4 mat4_adjoint(const Mat4 &m) {  // mat4.rs:567-606
+    Real m1 = A(2, 2) * A(3, 3) - A(2, 3) * A(3, 2), m2 = A(2, 1) * A(3, 3) - A(2, 3) * A(3, 1);
+    Real m3 = A(2, 1) * A(3, 2) - A(2, 2) * A(3, 1), m4 = A(0, 2) * A(1, 3) - A(0, 3) * A(1, 2);
+    Real m5 = A(0, 1) * A(1, 3) - A(0, 3) * A(1, 1), m6 = A(0, 1) * A(1, 2) - A(0, 2) * A(1, 1);
+    Real m7 = A(2, 0) * A(3, 3) - A(2, 3) * A(3, 0), m8 = A(2, 0) * A(3, 2) - A(2, 2) * A(3, 0);
+    Real m9 = A(1, 2) * A(3, 3) - A(1, 3) * A(3, 2), m10 = A(1, 0) * A(3, 3) - A(1, 3) * A(3, 0);
+    Real m11 = A(1, 0) * A(3, 2) - A(1, 2) * A(3, 0), m12 = A(0, 0) * A(1, 3) - A(0, 3) * A(1, 0);
+    Real m13 = A(0, 0) * A(1, 2) - A(0, 2) * A(1, 0), m14 = A(2, 0) * A(3, 1) - A(2, 1) * A(3, 0);
+    Real m15 = A(0, 0) * A(1, 1) - A(0, 1) * A(1, 0), m16 = A(2, 0) * A(3, 1) - A(2, 1) * A(3, 0);
+    Mat4 r{};
+    r.at(0, 0) = A(1, 1) * m1 - A(1, 2) * m2 + A(1, 3) * m3;   r.at(0, 1) = -A(0, 1) * m1 + A(0, 2) * m2 - A(0, 3) * m3;
+    r.at(0, 2) = A(3, 1) * m4 - A(3, 2) * m5 + A(3, 3) * m6;   r.at(0, 3) = -A(2, 1) * m4 + A(2, 2) * m5 - A(2, 3) * m6;
+    r.at(1, 0) = -A(1, 0) * m1 + A(1, 2) * m7 - A(1, 3) * m8;  r.at(1, 1) = A(0, 0) * m1 - A(0, 2) * m7 + A(0, 3) * m8;
+    r.at(1, 2) = -A(0, 0) * m9 + A(0, 2) * m10 - A(0, 3) * m11; r.at(1, 3) = A(2, 0) * m4 - A(2, 2) * m12 + A(2, 3) * m13;
+    r.at(2, 0) = A(1, 0) * m2 - A(1, 1) * m7 + A(1, 3) * m16;  r.at(2, 1) = -A(0, 0) * m2 + A(0, 1) * m7 - A(0, 3) * m16;
+    r.at(2, 2) = A(3, 0) * m5 - A(3, 1) * m12 + A(3, 3) * m15; r.at(2, 3) = -A(2, 0) * m5 + A(2, 1) * m12 - A(2, 3) * m15;
+    r.at(3, 0) = -A(1, 0) * m3 + A(1, 1) * m8 - A(1, 2) * m14; r.at(3, 1) = A(0, 0) * m3 - A(0, 1) * m8 + A(0, 2) * m14;
+    r.at(3, 2) = -A(3, 0) * m6 + A(3, 1) * m13 - A(3, 2) * m15; r.at(3, 3) = A(2, 0) * m6 - A(2, 1) * m13 + A(2, 2) * m15;
+    return r;
+}
+#undef A
+inline bool mat4_invert(const Mat4 &m, Mat4 *out) {  // mat4.rs:608-617 (asserts on det == 0)
+    Real d = mat4_det(m);
+    if (d == 0.0f) return false;
+    Real inv = 1.0f / d;
+    Mat4 adj = mat4_adjoint(m);
+    for (int i = 0; i < 16; ++i) out->a[i] = adj.a[i] * inv;
+    return true;
+}
+inline Mat4 mat4_transpose(const Mat4 &m) {  // mat4.rs:52-74
+    Mat4 t{};
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) t.at(r, c) = m.at(c, r);
+    return t;
+}
+inline Vec3 mat4_mul_vec4_xyz(const Mat4 &m, Vec3 v, Real w) {  // mat4.rs:434-441 followed by .xyz()
+    return V(m.at(0, 0) * v.x + m.at(0, 1) * v.y + m.at(0, 2) * v.z + m.at(0, 3) * w,
+             m.at(1, 0) * v.x + m.at(1, 1) * v.y + m.at(1, 2) * v.z + m.at(1, 3) * w,
+             m.at(2, 0) * v.x + m.at(2, 1) * v.y + m.at(2, 2) * v.z + m.at(2, 3) * w);
+}
+inline Aabb aabb_transform(const Mat4 &mat, const Aabb &b) {  // aabb3.rs:81-97 (vec4 min/max component-wise, xyz kept)
+    Aabb r;
+    Real lo[3], hi[3];
+    for (int row = 0; row < 3; ++row) {
+        Real xmin = mat.at(row, 0) * b.min.x, xmax = mat.at(row, 0) * b.max.x;
+        Real ymin = mat.at(row, 1) * b.min.y, ymax = mat.at(row, 1) * b.max.y;
+        Real zmin = mat.at(row, 2) * b.min.z, zmax = mat.at(row, 2) * b.max.z;
+        lo[row] = f32_min(xmin, xmax) + f32_min(ymin, ymax) + f32_min(zmin, zmax) + mat.at(row, 3);
+        hi[row] = f32_max(xmin, xmax) + f32_max(ymin, ymax) + f32_max(zmin, zmax) + mat.at(row, 3);
+    }
+    r.min = V(lo[0], lo[1], lo[2]); r.max = V(hi[0], hi[1], hi[2]);
+    return r;
+}
+
+struct Transform : Hittable {  // transform.rs:155-213
+    Mat4 obj2world, world2object, normal2world;
+    const Hittable *obj;
+    bool init(const Mat4 &o2w, const Hittable *o) {  // :163-175
+        obj = o;
+        obj2world = o2w;
+        if (!mat4_invert(o2w, &world2object)) return false;
+        normal2world = mat4_transpose(mat4_adjoint(world2object));
+        return true;
+    }
+    bool bounding_box(Real t0, Real t1, Aabb *out) const override {
+        Aabb b;
+        if (!obj->bounding_box(t0, t1, &b)) return false;
+        *out = aabb_transform(obj2world, b);
+        return true;
+    }
+    bool hit(const Ray &r, Real t_min, Real t_max, HitRecord *rec) const override {  // :184-204 + math/src/ray.rs:42-54
+        Ray transformed_ray{mat4_mul_vec4_xyz(world2object, r.origin, 1.0f), mat4_mul_vec4_xyz(world2object, r.direction, 0.0f), r.time};
+        HitRecord h;
+        if (!obj->hit(transformed_ray, t_min, t_max, &h)) return false;
+        *rec = h;
+        rec->p = mat4_mul_vec4_xyz(obj2world, h.p, 1.0f);
+        rec->normal = normalize(mat4_mul_vec4_xyz(normal2world, h.normal, 0.0f));
+        return true;
+    }
+    Real pdf_value(Vec3 o, Vec3 v) const override { return obj->pdf_value(o, v); }
+    Vec3 random(Vec3 v) const override { return obj->random(v); }
+};
+
+/* ------------------------------------------------------------------ math/src/polynomial.rs + the quadrics */
+inline uint32_t poly_quadratic(Real a, Real b, Real c, Real roots[2]) {  // polynomial.rs:11-39
+    if (a == 0.0f) {                     // poly_linear(b, c, roots), :3-9
+        if (b == 0.0f) return 0;
+        roots[0] = -c / b;
+        return 1;
+    }
+    Real delta = b * b - 4.0f * a * c;
+    if (delta == 0.0f) {
+        roots[0] = -b / 2.0f * a;        // sic
+        roots[1] = -b / 2.0f * a;
+        return 2;
+    }
+    if (!(delta < 0.0f)) {               // is_sign_positive; a NaN delta counts as positive whatever its sign bit:
+                                         // which sign an invalid operation gives NaN differs between x86 and the GPU
+        Real sgn = b != b ? b : std::copysign(1.0f, b);   // f32::signum
+        Real q = -(b + sgn * std::sqrt(delta)) / 2.0f;
+        roots[0] = q / a;
+        roots[1] = c / q;
+        if (roots[0] > roots[1]) std::swap(roots[0], roots[1]);
+        return 2;
+    }
+    return 0;
+}
+const Real C_TWO_PI = C_PI * 2.0f;       // types.rs:29
+inline Real atan2_positive(Real y, Real x, Real add) {  // `phi = y.atan2(x); if phi < 0 { phi += add }`
+    Real phi = m_atan2(y, x);
+    if (phi < 0.0f) phi = phi + add;
+    return phi;
+}
+
+struct Cylinder : Hittable {  // cylinder.rs
+    Real radius, zmin, zmax, phi_max;
+    const Material *mtl;
+    uint32_t prim_id;
+    bool hit(const Ray &r, Real t_min, Real t_max, HitRecord *rec) const override {  // :52-128
+        Real a = r.direction.x * r.direction.x + r.direction.y * r.direction.y;
+        Real b = 2.0f * (r.direction.x * r.origin.x + r.direction.y * r.origin.y);
+        Real c = r.origin.x * r.origin.x + r.origin.y * r.origin.y - radius * radius;
+        Real roots[2] = {0.0f, 0.0f};
+        if (poly_quadratic(a, b, c, roots) == 0) return false;
+        Real t0 = roots[0], t1 = roots[1];
+        if (t0 > t_max || t1 < t_min) return false;
+        Real thit = t0 < t_min ? t1 : t0;
+        if (thit > t_max) return false;
+        Vec3 p = r.at(thit);
+        Real phi = atan2_positive(p.y, p.x, 2.0f * C_PI);
+        if (p.z < zmin || p.z > zmax || phi > phi_max) {
+            if (thit == t1) return false;
+            thit = t1;
+            if (t1 > t_max) return false;
+            p = r.at(thit);
+            phi = atan2_positive(p.y, p.x, 2.0f * C_PI);
+            if (p.z < zmin || p.z > zmax || phi > phi_max) return false;
+        }
+        Real u = phi / phi_max, v = (p.z - zmin) / (zmax - zmin);
+        Vec3 dpdu = V(-phi_max * p.y, phi_max * p.x, 0.0f), dpdv = V(0.0f, 0.0f, zmax - zmin);
+        *rec = hit_record_new(p, normalize(cross(dpdv, dpdu)), r, thit, mtl, u, v, prim_id);
+        return true;
+    }
+    bool bounding_box(Real, Real, Aabb *out) const override { *out = Aabb{V(-radius, -radius, zmin), V(radius, radius, zmax)}; return true; }
+    // pdf_value / random (:134-161) are not restated: no scene puts a Cylinder into `lights`, and the scene
+    // loader rejects one there.
+};
+
+struct Cone : Hittable {  // cone.rs
+    Real radius, height, phi_max;
+    const Material *mtl;
+    uint32_t prim_id;
+    bool hit(const Ray &r, Real, Real t_max, HitRecord *rec) const override {  // :35-121 (t_min is ignored)
+        Real k = radius / height;
+        k = k * k;
+        Real a = r.direction.x * r.direction.x + r.direction.y * r.direction.y - k * r.direction.z * r.direction.z;
+        Real b = 2.0f * (r.direction.x * r.origin.x + r.direction.y * r.origin.y - k * r.direction.z * (r.origin.z - height));
+        Real c = r.origin.x * r.origin.x + r.origin.y * r.origin.y - k * (r.origin.z - height) * (r.origin.z - height);
+        Real roots[2] = {0.0f, 0.0f};
+        if (poly_quadratic(a, b, c, roots) == 0) return false;
+        Real t0 = roots[0], t1 = roots[1];
+        if (t0 > t_max || t1 <= 0.0f) return false;
+        Real thit = t0 <= 0.0f ? t1 : t0;
+        if (thit > t_max) return false;
+        Vec3 p = r.at(thit);
+        Real phi = atan2_positive(p.y, p.x, C_TWO_PI);
+        if (p.z < 0.0f || p.z > height || phi > phi_max) {
+            if (thit == t1) return false;
+            thit = t1;
+            if (thit > t_max) return false;
+            p = r.at(thit);
+            phi = atan2_positive(p.y, p.x, C_TWO_PI);
+            if (p.z < 0.0f || p.z > height || phi > phi_max) return false;
+        }
+        Real u = phi / phi_max, v = p.z / height;
+        Vec3 dpdu = V(-phi_max * p.y, phi_max * p.y, 0.0f);  // sic: p.y twice (:109)
+        Vec3 dpdv = V(-p.x / (1.0f - v), -p.y / (1.0f - v), height);
+        *rec = hit_record_new(p, normalize(cross(dpdu, dpdv)), r, thit, mtl, u, v, prim_id);
+        return true;
+    }
+    bool bounding_box(Real, Real, Aabb *out) const override { *out = Aabb{V(-radius, -radius, 0.0f), V(radius, radius, height)}; return true; }
+};
+
+struct Paraboloid : Hittable {  // paraboloid.rs
+    Real radius, zmin, zmax, phi_max;
+    const Material *mtl;
+    uint32_t prim_id;
+    bool bounding_box(Real, Real, Aabb *out) const override { *out = Aabb{V(-radius, -radius, zmin), V(radius, radius, zmax)}; return true; }
+    bool hit(const Ray &r, Real, Real t_max, HitRecord *rec) const override {  // :48-144 (t_min is ignored)
+        Real dx = r.direction.x, dy = r.direction.y, dz = r.direction.z, ox = r.origin.x, oy = r.origin.y, oz = r.origin.z;
+        Real k = zmax / (radius * radius);
+        Real a = k * (dx * dx + dy * dy);
+        Real b = 2.0f * k * (dx * ox + dy * oy) - dz;
+        Real c = k * (ox * ox + oy * oy) - oz;
+        Real roots[2] = {0.0f, 0.0f};
+        if (poly_quadratic(a, b, c, roots) == 0) return false;
+        Real t0 = roots[0], t1 = roots[1];
+        if (t0 > t_max || t1 <= 0.0f) return false;
+        Real thit = t0;
+        if (thit <= 0.0f) {
+            thit = t1;
+            if (thit > t_max) return false;
+        }
+        Vec3 phit = r.at(thit);
+        Real phi = atan2_positive(phit.y, phit.x, C_TWO_PI);
+        if (phit.z < zmin || phit.z > zmax || phi > phi_max) {
+            if (thit == t1) return false;
+            thit = t1;
+            if (t1 > t_max) return false;
+            phit = r.at(thit);
+            phi = atan2_positive(phit.y, phit.x, C_TWO_PI);
+            if (phit.z < zmin || phit.z > zmax || phi > phi_max) return false;
+        }
+        Real u = phi / phi_max, v = (phit.z - zmin) / (zmax - zmin);
+        Vec3 dpdu = V(-phi_max * phit.y, phi_max * phit.x, 0.0f);
+        Vec3 dpdv = (zmax - zmin) * V(phit.x / (2.0f * phit.z), phit.y / (2.0f * phit.z), 1.0f);
+        *rec = hit_record_new(phit, normalize(cross(dpdu, dpdv)), r, thit, mtl, u, v, prim_id);
+        return true;
+    }
+};
+
+struct Hyperboloid : Hittable {  // hyperboloid.rs
+    Vec3 p1, p2;
+    Real zmin, zmax, phi_max, rmax, ah, ch;
+    const Material *mtl;
+    uint32_t prim_id;
+    bool init(Vec3 a1, Vec3 a2, Real phimax) {  // :26-67
+        Real radius1 = std::sqrt(a1.x * a1.x + a1.y * a1.y), radius2 = std::sqrt(a2.x * a2.x + a2.y * a2.y);
+        rmax = f32_max(radius1, radius2);
+        zmin = f32_min(a1.z, a2.z); zmax = f32_max(a1.z, a2.z);
+        p1 = a1; p2 = a2;
+        if (a2.z == 0.0f) { p1 = a2; p2 = a1; }
+        phi_max = phimax;
+        Vec3 pp = p1;
+        for (int it = 0; it < 64; ++it) {  // `loop` in the reference; bounded here
+            pp = pp + 2.0f * (p2 - p1);
+            Real xy1 = pp.x * pp.x + pp.y * pp.y, xy2 = p2.x * p2.x + p2.y * p2.y;
+            ah = (1.0f / xy1 - (pp.z * pp.z) / (xy1 * p2.z * p2.z)) / (1.0f - (xy2 * pp.z * pp.z) / (xy1 * p2.z * p2.z));
+            ch = (ah * xy2 - 1.0f) / (p2.z * p2.z);
+            if (!std::isinf(ah) && !std::isnan(ah)) return true;
+        }
+        return false;
+    }
+    bool bounding_box(Real, Real, Aabb *out) const override { *out = Aabb{V(-rmax, -rmax, zmin), V(rmax, rmax, zmax)}; return true; }
+    Real phi_of(Vec3 phit, Real *v, Real add) const {  // :112-117, 134-139
+        *v = (phit.z - p1.z) / (p2.z - p1.z);
+        Vec3 pr = (1.0f - *v) * p1 + *v * p2;
+        return atan2_positive(pr.x * phit.y - phit.x * pr.y, phit.x * pr.x + phit.y * pr.y, add);
+    }
+    bool hit(const Ray &r, Real, Real t_max, HitRecord *rec) const override {  // :78-169 (t_min is ignored)
+        Real ox = r.origin.x, oy = r.origin.y, oz = r.origin.z, dx = r.direction.x, dy = r.direction.y, dz = r.direction.z;
+        Real a = ah * dx * dx + ah * dy * dy - ch * dz * dz;
+        Real b = 2.0f * (ah * dx * ox + ah * dy * oy - ch * dz * oz);
+        Real c = ah * ox * ox + ah * oy * oy - ch * oz * oz - 1.0f;
+        Real roots[2] = {0.0f, 0.0f};
+        if (poly_quadratic(a, b, c, roots) == 0) return false;
+        Real t0 = roots[0], t1 = roots[1];
+        if (t0 > t_max || t1 <= 0.0f) return false;
+        Real thit = t0;
+        if (thit <= 0.0f) {
+            thit = t1;
+            if (thit > t_max) return false;
+        }
+        Vec3 phit = r.at(thit);
+        Real v;
+        Real phi = phi_of(phit, &v, 2.0f);  // sic: += C_TWO, not C_TWO_PI (:116)
+        if (phit.z < zmin || phit.z > zmax || phi > phi_max) {
+            if (thit == t1) return false;
+            thit = t1;
+            if (t1 > t_max) return false;
+            phit = r.at(thit);
+            phi = phi_of(phit, &v, C_TWO_PI);
+            if (phit.z < zmin || phit.z > zmax || phi > phi_max) return false;
+        }
+        Real u = phi / phi_max;
+        Real sin_phi, cos_phi;
+        m_sincos(phi, &sin_phi, &cos_phi);
+        Vec3 dpdu = V(-phi_max * phit.y, phi_max * phit.x, 0.0f);
+        Vec3 dpdv = V((p2.x - p1.x) * cos_phi - (p2.y - p1.y) * sin_phi, (p2.x - p1.x) * sin_phi + (p2.y - p1.y) * cos_phi, p2.z - p1.z);
+        *rec = hit_record_new(phit, normalize(cross(dpdu, dpdv)), r, thit, mtl, u, v, prim_id);
+        return true;
+    }
+};
+
 /* ------------------------------------------------------------------ bvh.rs */
 bool g_bvh_exhaustive = false;
 
@@ -940,6 +1240,46 @@ struct orc_scene {
             res = r;
             break;
         }
+        case RTG_TRANSFORM: {
+            const Hittable *c = build(ch[0], number, depth + 1);
+            if (!c) return nullptr;
+            Mat4 o2w{};
+            memcpy(o2w.a, n.f, 12 * sizeof(float));
+            o2w.at(3, 3) = 1.0f;
+            Transform *t = own(new Transform());
+            if (!t->init(o2w, c)) { err = "Matrix is not invertible"; return nullptr; }
+            res = t;
+            break;
+        }
+        case RTG_CYLINDER: {
+            take_id();
+            Cylinder *q = own(new Cylinder());
+            q->radius = n.f[0]; q->zmin = n.f[1]; q->zmax = n.f[2]; q->phi_max = n.f[3]; q->mtl = mat(n.material); q->prim_id = pid;
+            res = q;
+            break;
+        }
+        case RTG_CONE: {
+            take_id();
+            Cone *q = own(new Cone());
+            q->radius = n.f[0]; q->height = n.f[1]; q->phi_max = n.f[2]; q->mtl = mat(n.material); q->prim_id = pid;
+            res = q;
+            break;
+        }
+        case RTG_PARABOLOID: {
+            take_id();
+            Paraboloid *q = own(new Paraboloid());
+            q->radius = n.f[0]; q->zmin = n.f[1]; q->zmax = n.f[2]; q->phi_max = n.f[3]; q->mtl = mat(n.material); q->prim_id = pid;
+            res = q;
+            break;
+        }
+        case RTG_HYPERBOLOID: {
+            take_id();
+            Hyperboloid *q = own(new Hyperboloid());
+            if (!q->init(V(n.f[0], n.f[1], n.f[2]), V(n.f[3], n.f[4], n.f[5]), n.f[6])) { err = "Hyperboloid without finite coefficients"; return nullptr; }
+            q->mtl = mat(n.material); q->prim_id = pid;
+            res = q;
+            break;
+        }
         case RTG_BVH: {
             std::vector<const Hittable *> l;
             for (int i = 0; i < n.child_count; ++i) {
@@ -1008,12 +1348,14 @@ struct GlobalOptions {  // options live in globals read by the object code; set 
     }
 };
 
+std::atomic<int> g_trace{getenv("ORC_TRACE") != nullptr ? 1 : 0};   // env ORC_TRACE or orc_set_trace()
+
 // camera.rs:253-309
 Color ray_color(const Ray &r, Color background, const HittableList &world, const Hittable *lights, int depth) {
     if (depth <= 0) return C(0, 0, 0);
     ++tl_rays;
     HitRecord rec;
-    static const bool trace = getenv("ORC_TRACE") != nullptr;   // debugging aid: one line per bounce on stderr
+    const bool trace = g_trace.load(std::memory_order_relaxed) != 0;   // debugging aid: one line per bounce on stderr
     if (!world.hit(r, 0.001f, INFINITY, &rec)) {
         if (trace) fprintf(stderr, "[orc] depth %d ray %.9g %.9g %.9g | %.9g %.9g %.9g | %.9g miss\n", depth, r.origin.x, r.origin.y, r.origin.z,
                            r.direction.x, r.direction.y, r.direction.z, r.time);
@@ -1119,6 +1461,8 @@ extern "C" {
 const char *orc_last_error(void) { return g_error.c_str(); }
 
 // KAT hook: the ray of get_ray_<projection>(u, v) with lens sample (dx, dy); out6 = origin, direction; 0 = None
+void orc_set_trace(int on) { g_trace.store(on ? 1 : 0); }
+
 int orc_project(const orc_render_params *p, float u, float v, float dx, float dy, float *out6) {
     Ray r{V(0, 0, 0), V(0, 0, 0), 0.0f};
     if (!project(*p, u, v, Vec2{dx, dy}, r)) return 0;

@@ -52,6 +52,8 @@ typedef struct orc_render_params {
 /* KAT hook: the ray of get_ray_<projection>(u, v) (camera.rs:82-184) with unit-disk lens sample (dx, dy);
  * out6 = origin, direction.  Returns 0 for FishEye's None. */
 int orc_project(const orc_render_params *p, float u, float v, float dx, float dy, float *out6);
+/* Debugging aid: print one line per bounce of every traced path on stderr (also: env ORC_TRACE). */
+void orc_set_trace(int on);
 
 int orc_render(const orc_scene *s, const orc_render_params *p, const rt_sampler_desc *sampler, float *out_rgba_sum,
                uint64_t *rays_out, uint32_t *pixel_rays);

@@ -46,6 +46,7 @@ class rt_scene_desc(C.Structure):
         ("moving_slots", c_u32_p), ("n_moving_slots", C.c_uint32),
         ("rect_slots", c_u32_p), ("n_rect_slots", C.c_uint32),
         ("n_prims", C.c_uint32),
+        ("matrices", c_float_p), ("n_matrices", C.c_uint32),
     ]
 
 
@@ -81,7 +82,7 @@ class rt_render_params(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64), ("box_tests", C.c_uint64),
-                ("prim_tests", C.c_uint64 * 6), ("medium_tests", C.c_uint64), ("light_pdf_evals", C.c_uint64),
+                ("prim_tests", C.c_uint64 * 10), ("medium_tests", C.c_uint64), ("light_pdf_evals", C.c_uint64),
                 ("shades", C.c_uint64 * 5), ("tex_evals", C.c_uint64 * 4), ("accepted_hits", C.c_uint64),
                 ("phase_lanes", C.c_uint64 * 5), ("phase_slots", C.c_uint64 * 5)]
 
@@ -142,7 +143,8 @@ class rth_image(C.Structure):
 
 class rth_scene_assets(C.Structure):
     _fields_ = [("earthmap", rth_image), ("uvgrid01", rth_image), ("uvgrid09", rth_image),
-                ("teapot", C.c_void_p), ("mesh_grid", C.c_int32)]
+                ("teapot", C.c_void_p), ("mesh_grid", C.c_int32),
+                ("uvgrid03", rth_image), ("uvgrid08", rth_image), ("uvgrid10", rth_image)]
 
 
 class rth_user_config(C.Structure):
@@ -163,7 +165,8 @@ HOST_SYMBOLS = [
     "rth_geometry_free", "rth_geometry_view", "rth_build_scene", "rth_config_load", "rth_config_parse",
     "rth_config_free", "rth_config_active_scene", "rth_config_scene_params", "rth_image_height", "rth_camera_new",
     "rth_sampler_new", "rth_sampler_free", "rth_sampler_desc", "rth_flatten", "rth_flat_free", "rth_flat_desc",
-    "rth_work_blocks", "rth_mat4_mul", "rth_mat4_invert",
+    "rth_work_blocks", "rth_mat4_mul", "rth_mat4_invert", "rth_add_transform", "rth_add_cylinder", "rth_add_cone",
+    "rth_add_paraboloid", "rth_add_hyperboloid",
 ]
 
 HIP_SYMBOLS = [
@@ -212,6 +215,11 @@ def host_lib():
     L.rth_add_constant_medium.argtypes = [vp, i32, i32, f]
     L.rth_add_triangle_mesh.argtypes = [vp, C.POINTER(rtg_vertex), u32, c_u32_p, u32, C.POINTER(rtg_mesh_node), u32,
                                         C.c_float * 16, i32]
+    L.rth_add_transform.argtypes = [vp, i32, C.c_float * 16]
+    L.rth_add_cylinder.argtypes = [vp, f, f, f, f, i32]
+    L.rth_add_cone.argtypes = [vp, f, f, f, i32]
+    L.rth_add_paraboloid.argtypes = [vp, f, f, f, f, i32]
+    L.rth_add_hyperboloid.argtypes = [vp, f3, f3, f, i32]
     L.rth_set_roots.argtypes = [vp, i32, i32]
     L.rth_geometry_import_glb.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.rth_geometry_free.argtypes = [vp]

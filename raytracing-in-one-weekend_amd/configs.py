@@ -6,6 +6,9 @@ image size / spp of BASELINE.json on top:
   C2  CornellBox      600x600 1000 spp   default_params camera, aspect 1.0
   C3  Chapter2Final   800x800  10k spp   config camera
   C4  MeshTest       1920x1080 256 spp   config camera, K x K teapots (K=10 -> 2.26 M triangles)
+and the reference's two remaining scenes with their shipped configs:
+  GP      GeometricPrimitives  800x600 256 spp  SphericalPanoramic camera; blocks, cylinders, cones, paraboloids
+  BLOCKS  Blocks               800x600 256 spp  three checkered blocks under general Transforms
 """
 from . import host
 
@@ -16,6 +19,8 @@ WORKLOADS = {
     "C2": dict(scene="CornellBox", image_width=600, aspect_ratio=1.0, samples_per_pixel=1000),
     "C3": dict(scene="Chapter2Final", image_width=800, aspect_ratio=1.0, samples_per_pixel=10000),
     "C4": dict(scene="MeshTest", image_width=1920, aspect_ratio=1920.0 / 1080.0, samples_per_pixel=256, mesh_grid=10),
+    "GP": dict(scene="GeometricPrimitives"),
+    "BLOCKS": dict(scene="Blocks"),
 }
 
 
@@ -34,7 +39,8 @@ def build(name, config=None, seed=SEED, **overrides):
     """Build everything a render needs: (Scene, RaytracerParams, rt_camera, MultiJitteredSampler)."""
     scene_name, params, mesh_grid = workload(name, config, **overrides)
     need = {"RandomWorld": (), "CornellBox": (), "Chapter2Final": ("earthmap",),
-            "MeshTest": ("uvgrid01", "uvgrid09", "teapot")}[scene_name]
+            "MeshTest": ("uvgrid01", "uvgrid09", "teapot"), "Blocks": ("uvgrid01",),
+            "GeometricPrimitives": ("uvgrid01", "uvgrid03", "uvgrid08", "uvgrid10")}[scene_name]
     assets = host.Assets(mesh_grid=mesh_grid, need=need) if need else None
     scene = host.Scene.build(scene_name, seed, assets)
     sampler = host.MultiJitteredSampler(params.samples_per_pixel, seed=seed)

@@ -280,7 +280,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
         fprintf(stderr, "[rt-regions]");
-        for (int i = 0; i < RT_N_REGIONS; ++i) fprintf(stderr, " %llu", h[32 + i]);
+        for (int i = 0; i < RT_N_REGIONS; ++i) fprintf(stderr, " %llu", h[RT_STAT_WORDS + 1 + i]);
         fprintf(stderr, "\n");
     }
     return RT_OK;
@@ -370,8 +370,19 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         memcpy(&w4, &s->slots[i * RT_SLOT_FLOATS + 4], 4);
         memcpy(&mat, &s->slots[i * RT_SLOT_FLOATS + 5], 4);
         int type = w4 & 15, xf = (w4 >> 8) - 1;
-        if (type > RT_PRIM_TRIANGLE) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "slot %u: primitive type %d", i, type);
+        if (type > RT_PRIM_HYPERBOLOID) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "slot %u: primitive type %d", i, type);
         if (xf >= (int)s->n_xforms) return fail(ctx, RT_E_INVALID, "slot %u: xform out of range", i);
+        bool general = false;
+        if (xf >= 0) {
+            int32_t flags, m;
+            memcpy(&flags, &s->xforms[(size_t)xf * RT_REC_FLOATS], 4);
+            memcpy(&m, &s->xforms[(size_t)xf * RT_REC_FLOATS + 1], 4);
+            general = (flags & 4) != 0;
+            if (general && (m < 0 || (uint32_t)m >= s->n_matrices || !s->matrices)) return fail(ctx, RT_E_INVALID, "slot %u: matrix out of range", i);
+        }
+        // the traversal kernel does not carry the code for these (rt_kernels.h slot_hit_rec<STATS, false>)
+        if ((general || type >= RT_PRIM_CYLINDER) && !(i >= s->always_begin && i - s->always_begin < s->always_count))
+            return fail(ctx, RT_E_INVALID, "slot %u: quadrics and slots under a general Transform must be in the always-list", i);
         if (mat < 0 || (uint32_t)mat >= s->n_materials) return fail(ctx, RT_E_INVALID, "slot %u: material out of range", i);
         tris |= type == RT_PRIM_TRIANGLE;
     }
@@ -420,7 +431,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
             int32_t w4;
             memcpy(&w4, &dev_slots[(size_t)i * RT_SLOT_FLOATS + 4], 4);
             int type = w4 & 15, xf = (w4 >> 8) - 1;
-            if (xf >= 0 && type != RT_PRIM_MOVING_SPHERE && type != RT_PRIM_TRIANGLE)
+            if (xf >= 0 && type_has_inline_xform(type))
                 memcpy(&dev_slots[(size_t)i * RT_SLOT_FLOATS + 8], &s->xforms[(size_t)xf * RT_REC_FLOATS], RT_REC_FLOATS * 4);
         }
         UP(slots, dev_slots.data(), dev_slots.size() * 4);
@@ -428,6 +439,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     }
     UP(attrs, s->tri_attrs, tris ? (size_t)s->n_slots * RT_ATTR_FLOATS * 4 : 0);
     UP(xforms, s->xforms, (size_t)s->n_xforms * RT_REC_FLOATS * 4);
+    UP(matrices, s->matrices, (size_t)s->n_matrices * RT_MATRIX_FLOATS * 4);
     UP(media, s->media, (size_t)s->n_media * RT_REC_FLOATS * 4);
     UP(lights, s->lights, (size_t)s->n_lights * RT_REC_FLOATS * 4);
     {   // device copy of the materials: word 7 = kind of the material's texture + 1 (0 = untextured), and a solid
@@ -564,12 +576,13 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
         memset(stats, 0, sizeof *stats);
         stats->paths = h_stats[0]; stats->rays = h_stats[1]; stats->node_visits = h_stats[2];
         stats->box_tests = 2 * h_stats[2];
-        for (int i = 0; i < 6; ++i) stats->prim_tests[i] = h_stats[3 + i];
-        stats->medium_tests = h_stats[9]; stats->light_pdf_evals = h_stats[10];
-        for (int i = 0; i < 5; ++i) stats->shades[i] = h_stats[11 + i];
-        for (int i = 0; i < 4; ++i) stats->tex_evals[i] = h_stats[16 + i];
-        stats->accepted_hits = h_stats[20];
-        for (int i = 0; i < 5; ++i) { stats->phase_lanes[i] = h_stats[21 + i]; stats->phase_slots[i] = h_stats[26 + i]; }
+        constexpr int P = RT_N_PRIM_TYPES;   // order: flush_counters (rt_wavefront.h)
+        for (int i = 0; i < P; ++i) stats->prim_tests[i] = h_stats[3 + i];
+        stats->medium_tests = h_stats[3 + P]; stats->light_pdf_evals = h_stats[4 + P];
+        for (int i = 0; i < 5; ++i) stats->shades[i] = h_stats[5 + P + i];
+        for (int i = 0; i < 4; ++i) stats->tex_evals[i] = h_stats[10 + P + i];
+        stats->accepted_hits = h_stats[14 + P];
+        for (int i = 0; i < 5; ++i) { stats->phase_lanes[i] = h_stats[15 + P + i]; stats->phase_slots[i] = h_stats[20 + P + i]; }
     }
     return RT_OK;
 }

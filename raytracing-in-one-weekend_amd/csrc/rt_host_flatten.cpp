@@ -49,7 +49,7 @@ struct Wrap {
     bool has_rot = false, has_trans = false;
     float sin_t = 0, cos_t = 1;
     float off[3] = {0, 0, 0};
-    int xform = -1;
+    int matrix = -1;         // general Transform (transform.rs:155-213): index into rth_flat::matrices
 };
 
 }  // namespace
@@ -58,7 +58,7 @@ struct rth_flat {
     std::vector<Slot> slots;
     std::vector<Attr> attrs;
     std::vector<float> nodes;  // RT_NODE_FLOATS each
-    std::vector<float> xforms, media, lights, materials, textures;
+    std::vector<float> xforms, matrices, media, lights, materials, textures;
     std::vector<uint32_t> perlin;
     std::vector<uint8_t> texels;
     std::vector<uint32_t> moving, rects;
@@ -75,6 +75,7 @@ struct Flattener {
     std::vector<Slot> prims;   // in primitive-id order (before BVH reordering)
     std::vector<Attr> pattrs;
     std::vector<Box> boxes;
+    std::vector<uint8_t> always;   // per primitive: tested for every ray, never through the BVH (rt_api.h rt_prim_type)
     uint32_t next_id = 0;
     std::string err;
 
@@ -84,11 +85,15 @@ struct Flattener {
     }
 
     int xform_index(const Wrap &w) {
-        if (!w.has_rot && !w.has_trans) return -1;
+        if (!w.has_rot && !w.has_trans && w.matrix < 0) return -1;
         float rec[RT_REC_FLOATS] = {};
-        rec[0] = i2f((w.has_rot ? 1 : 0) | (w.has_trans ? 2 : 0));
-        rec[1] = w.sin_t; rec[2] = w.cos_t;
-        rec[3] = w.off[0]; rec[4] = w.off[1]; rec[5] = w.off[2];
+        if (w.matrix >= 0) {
+            rec[0] = i2f(4); rec[1] = i2f(w.matrix);
+        } else {
+            rec[0] = i2f((w.has_rot ? 1 : 0) | (w.has_trans ? 2 : 0));
+            rec[1] = w.sin_t; rec[2] = w.cos_t;
+            rec[3] = w.off[0]; rec[4] = w.off[1]; rec[5] = w.off[2];
+        }
         for (size_t i = 0; i + RT_REC_FLOATS <= out->xforms.size(); i += RT_REC_FLOATS)
             if (memcmp(&out->xforms[i], rec, sizeof rec) == 0) return (int)(i / RT_REC_FLOATS);
         out->xforms.insert(out->xforms.end(), rec, rec + RT_REC_FLOATS);
@@ -102,6 +107,12 @@ struct Flattener {
         r.reset();
         for (int i = 0; i < 8; ++i) {
             float p[3] = {(i & 1) ? b.hi[0] : b.lo[0], (i & 2) ? b.hi[1] : b.lo[1], (i & 4) ? b.hi[2] : b.lo[2]};
+            if (w.matrix >= 0) {
+                const float *m = &out->matrices[(size_t)w.matrix * RT_MATRIX_FLOATS + 12];   // obj2world
+                float q[3];
+                for (int a = 0; a < 3; ++a) q[a] = m[4 * a] * p[0] + m[4 * a + 1] * p[1] + m[4 * a + 2] * p[2] + m[4 * a + 3];
+                for (int a = 0; a < 3; ++a) p[a] = q[a];
+            }
             if (w.has_rot) {
                 float x = w.cos_t * p[0] + w.sin_t * p[2], z = -w.sin_t * p[0] + w.cos_t * p[2];
                 p[0] = x; p[2] = z;
@@ -129,6 +140,7 @@ struct Flattener {
         float pad = 1.0e-4f * m;
         for (int a = 0; a < 3; ++a) { wb.lo[a] -= pad; wb.hi[a] += pad; }
         prims.push_back(s);
+        always.push_back((type >= RT_PRIM_CYLINDER || w.matrix >= 0) ? 1 : 0);
         Attr a{};
         if (attr) a = *attr;
         pattrs.push_back(a);
@@ -189,21 +201,56 @@ struct Flattener {
             emit_rect(RTG_YZ_RECT, yz1, w, n.material); emit_rect(RTG_YZ_RECT, yz0, w, n.material);
             return true;
         }
+        case RTG_CYLINDER: case RTG_PARABOLOID: {   // cylinder.rs:41, paraboloid.rs:41-46: box = [-r, r]^2 x [zmin, zmax]
+            float q0[4] = {n.f[0], n.f[1], n.f[2], n.f[3]};
+            Box b{{-n.f[0], -n.f[0], n.f[1]}, {n.f[0], n.f[0], n.f[2]}};
+            emit(n.type == RTG_CYLINDER ? RT_PRIM_CYLINDER : RT_PRIM_PARABOLOID, w, n.material, q0, 0.0f, nullptr, b, nullptr);
+            return true;
+        }
+        case RTG_CONE: {                            // cone.rs:123-128
+            float q0[4] = {n.f[0], n.f[1], 0.0f, n.f[2]};
+            Box b{{-n.f[0], -n.f[0], 0.0f}, {n.f[0], n.f[0], n.f[1]}};
+            emit(RT_PRIM_CONE, w, n.material, q0, 0.0f, nullptr, b, nullptr);
+            return true;
+        }
+        case RTG_HYPERBOLOID: {                     // hyperboloid.rs:26-76
+            float d[11];
+            if (!hyperboloid_derive(n.f, n.f + 3, d)) return fail("Hyperboloid without finite coefficients");
+            float q0[4] = {d[0], d[1], d[2], n.f[6]}, q2[4] = {d[3], d[4], d[5], d[7]};
+            Box b{{-d[8], -d[8], d[6]}, {d[8], d[8], d[7]}};
+            emit(RT_PRIM_HYPERBOLOID, w, n.material, q0, d[6], q2, b, nullptr);
+            prims.back().w[12] = d[9]; prims.back().w[13] = d[10];   // ah, ch
+            return true;
+        }
+        case RTG_TRANSFORM: {
+            if (n.child_count != 1) return fail("Transform needs one child");
+            if (w.has_trans || w.has_rot || w.matrix >= 0) return fail("unsupported wrapper nesting: Transform under Translate/RotateY/Transform");
+            M4 o2w = m4_identity(), w2o;
+            memcpy(o2w.a, n.f, 12 * sizeof(float));
+            if (!m4_invert(o2w, &w2o)) return fail("Matrix is not invertible");          // transform.rs:166
+            M4 n2w = m4_transpose(m4_adjoint(w2o));                                       // transform.rs:171
+            w.matrix = (int)(out->matrices.size() / RT_MATRIX_FLOATS);
+            out->matrices.insert(out->matrices.end(), w2o.a, w2o.a + 12);
+            out->matrices.insert(out->matrices.end(), o2w.a, o2w.a + 12);
+            out->matrices.insert(out->matrices.end(), n2w.a, n2w.a + 12);
+            return walk(ch[0], w, depth + 1);
+        }
         case RTG_FLIP_FACE:
             // A FlipFace under a Translate is overwritten by Translate's HitRecord::new
-            // (transform.rs:36-44), so only flips met before the Translate count.
+            // (transform.rs:36-44), so only flips met before the Translate count.  Transform keeps the
+            // inner front_face (transform.rs:198-202), so a flip on either side of it counts.
             if (n.child_count != 1) return fail("FlipFace needs one child");
             if (!w.has_trans) w.flip = !w.flip;
             return walk(ch[0], w, depth + 1);
         case RTG_TRANSLATE:
             if (n.child_count != 1) return fail("Translate needs one child");
-            if (w.has_trans || w.has_rot) return fail("unsupported wrapper nesting: Translate under Translate/RotateY");
+            if (w.has_trans || w.has_rot || w.matrix >= 0) return fail("unsupported wrapper nesting: Translate under Translate/RotateY/Transform");
             w.has_trans = true;
             w.off[0] = n.f[0]; w.off[1] = n.f[1]; w.off[2] = n.f[2];
             return walk(ch[0], w, depth + 1);
         case RTG_ROTATE_Y: {
             if (n.child_count != 1) return fail("RotateY needs one child");
-            if (w.has_rot) return fail("unsupported wrapper nesting: RotateY under RotateY");
+            if (w.has_rot || w.matrix >= 0) return fail("unsupported wrapper nesting: RotateY under RotateY/Transform");
             float rads = (n.f[0] * 3.14159265358979323846f) / 180.0f;  // types.rs:44-46
             pm::sincosf_(rads, &w.sin_t, &w.cos_t);
             w.has_rot = true;
@@ -215,7 +262,7 @@ struct Flattener {
             return true;
         case RTG_CONSTANT_MEDIUM: {
             if (n.child_count != 1) return fail("ConstantMedium needs one boundary");
-            if (w.has_rot || w.has_trans || w.flip) return fail("ConstantMedium under a wrapper is not supported");
+            if (w.has_rot || w.has_trans || w.flip || w.matrix >= 0) return fail("ConstantMedium under a wrapper is not supported");
             const rtg_node &b = g->nodes[ch[0]];
             if (b.type != RTG_SPHERE) return fail("ConstantMedium boundary must be a Sphere");
             float rec[RT_REC_FLOATS] = {b.f[0], b.f[1], b.f[2], b.f[3], -1.0f / n.f[0] /* constant_medium.rs:24 */,
@@ -263,10 +310,10 @@ struct Flattener {
             rec[0] = i2f(n.type == RTG_XY_RECT ? RT_PRIM_XY_RECT : n.type == RTG_XZ_RECT ? RT_PRIM_XZ_RECT : RT_PRIM_YZ_RECT);
             for (int i = 0; i < 5; ++i) rec[1 + i] = n.f[i];
             break;
-        case RTG_TRANSLATE: case RTG_ROTATE_Y:
+        case RTG_TRANSLATE: case RTG_ROTATE_Y: case RTG_TRANSFORM:   // transform.rs:48-54, 146-152, 206-212
             return light(g->children[n.child_begin], depth + 1);
-        case RTG_MOVING_SPHERE: case RTG_LIST:
-            return fail("MovingSphere / nested list in `lights` is not supported");
+        case RTG_MOVING_SPHERE: case RTG_LIST: case RTG_CYLINDER:
+            return fail("MovingSphere / Cylinder / nested list in `lights` is not supported");
         default:
             rec[0] = i2f(255);
             break;
@@ -404,7 +451,7 @@ int rth_flatten(const rtg_graph *g, rth_flat **out_flat) {
     if (!g || !out_flat) { set_error("null argument"); return RT_E_INVALID; }
     if (g->world_root < 0 || g->lights_root < 0) { set_error("scene roots are not set"); return RT_E_INVALID; }
     auto flat = std::make_unique<rth_flat>();
-    Flattener fl{g, flat.get(), {}, {}, {}, 0, {}};
+    Flattener fl{g, flat.get(), {}, {}, {}, {}, 0, {}};
     if (!fl.walk(g->world_root, Wrap{}, 0)) {
         set_error("flatten: %s", fl.err.c_str());
         return RT_E_UNSUPPORTED_PRIMITIVE;
@@ -460,34 +507,40 @@ int rth_flatten(const rtg_graph *g, rth_flat **out_flat) {
     }
 
     // BVH + slot order
-    size_t n = fl.prims.size();
-    std::vector<uint32_t> new_index(n);
+    const size_t n_all = fl.prims.size();
+    std::vector<uint32_t> new_index(n_all);
+    std::vector<uint32_t> in_bvh, in_always;   // primitive indices
+    for (size_t i = 0; i < n_all; ++i) (fl.always[i] ? in_always : in_bvh).push_back((uint32_t)i);
+    const size_t n = in_bvh.size();
     if (n <= 16) {  // tiny scenes (Cornell box: 13 leaves): a flat scan beats any tree
         flat->slots = fl.prims;
         flat->attrs = fl.pattrs;
         std::iota(new_index.begin(), new_index.end(), 0u);
         flat->always_begin = 0;
-        flat->always_count = (uint32_t)n;
+        flat->always_count = (uint32_t)n_all;
         flat->root_ref = RT_BVH_EMPTY;
         flat->stack_depth = 1;
     } else {
-        BvhBuilder bb(fl.boxes);
+        std::vector<Box> bvh_boxes(n);
+        for (size_t i = 0; i < n; ++i) bvh_boxes[i] = fl.boxes[in_bvh[i]];
+        BvhBuilder bb(bvh_boxes);
         bb.order.resize(n);
         std::iota(bb.order.begin(), bb.order.end(), 0u);
         bb.cx.resize(n); bb.cy.resize(n); bb.cz.resize(n);
         for (size_t i = 0; i < n; ++i) {
-            bb.cx[i] = 0.5f * (fl.boxes[i].lo[0] + fl.boxes[i].hi[0]);
-            bb.cy[i] = 0.5f * (fl.boxes[i].lo[1] + fl.boxes[i].hi[1]);
-            bb.cz[i] = 0.5f * (fl.boxes[i].lo[2] + fl.boxes[i].hi[2]);
+            bb.cx[i] = 0.5f * (bvh_boxes[i].lo[0] + bvh_boxes[i].hi[0]);
+            bb.cy[i] = 0.5f * (bvh_boxes[i].lo[1] + bvh_boxes[i].hi[1]);
+            bb.cz[i] = 0.5f * (bvh_boxes[i].lo[2] + bvh_boxes[i].hi[2]);
         }
         bb.nodes.reserve(n);
         int32_t root = bb.build(0, (uint32_t)n, 0);
-        flat->slots.resize(n);
-        flat->attrs.resize(n);
-        for (size_t i = 0; i < n; ++i) {
-            flat->slots[i] = fl.prims[bb.order[i]];
-            flat->attrs[i] = fl.pattrs[bb.order[i]];
-            new_index[bb.order[i]] = (uint32_t)i;
+        flat->slots.resize(n_all);
+        flat->attrs.resize(n_all);
+        for (size_t i = 0; i < n_all; ++i) {   // BVH leaves in leaf order, then the always-list in primitive order
+            const uint32_t prim = i < n ? in_bvh[bb.order[i]] : in_always[i - n];
+            flat->slots[i] = fl.prims[prim];
+            flat->attrs[i] = fl.pattrs[prim];
+            new_index[prim] = (uint32_t)i;
         }
         auto leaf_ref = [&](int32_t r) -> int32_t {
             if (r >= 0) return r;
@@ -557,7 +610,8 @@ int rth_flatten(const rtg_graph *g, rth_flat **out_flat) {
         flat->nodes.clear();
         flat->root_ref = root >= 0 ? collapse(root, 1) : leaf_ref(root);
         flat->stack_depth = 3 * max_depth4 + 2;   // a visit pushes at most three children
-        flat->always_begin = flat->always_count = 0;
+        flat->always_begin = (uint32_t)n;
+        flat->always_count = (uint32_t)in_always.size();
     }
     for (auto &m : flat->moving) m = new_index[m];
     for (auto &m : flat->rects) m = new_index[m];
@@ -577,6 +631,7 @@ void rth_flat_desc(const rth_flat *f, rt_scene_desc *d) {
     d->always_begin = f->always_begin;         d->always_count = f->always_count;
     d->tri_attrs = f->attrs.empty() ? nullptr : f->attrs[0].w;
     d->xforms = f->xforms.data();              d->n_xforms = (uint32_t)(f->xforms.size() / RT_REC_FLOATS);
+    d->matrices = f->matrices.data();          d->n_matrices = (uint32_t)(f->matrices.size() / RT_MATRIX_FLOATS);
     d->media = f->media.data();                d->n_media = (uint32_t)(f->media.size() / RT_REC_FLOATS);
     d->lights = f->lights.data();              d->n_lights = (uint32_t)(f->lights.size() / RT_REC_FLOATS);
     d->materials = f->materials.data();        d->n_materials = (uint32_t)(f->materials.size() / RT_REC_FLOATS);

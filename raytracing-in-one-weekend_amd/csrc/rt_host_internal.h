@@ -29,6 +29,8 @@ inline V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
 inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline float length_squared(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+inline float f32_min(float a, float b) { return a != a ? b : (b != b ? a : (a < b ? a : b)); }  // f32::min
+inline float f32_max(float a, float b) { return a != a ? b : (b != b ? a : (a > b ? a : b)); }  // f32::max
 // math/src/vec3.rs:690-700
 inline V3 normalize(V3 v) {
     float lensq = length_squared(v);
@@ -55,6 +57,8 @@ M4 m4_translate(V3 t);                        // mat4.rs:76-101
 M4 m4_scale(V3 s);                            // mat4.rs:103-125
 M4 quat_to_rotation_matrix(float w, float x, float y, float z);     // quat.rs:266-298
 void quat_axis_angle(float angle_deg, V3 axis, float q[4] /*w,x,y,z*/);  // quat.rs:66-88
+// Hyperboloid::new (hyperboloid.rs:26-67): out = p1 xyz, p2 xyz (after the swap), zmin, zmax, rmax, ah, ch
+bool hyperboloid_derive(const float p1[3], const float p2[3], float out[11]);
 
 struct Mesh {
     std::vector<rtg_vertex> verts;

@@ -164,6 +164,28 @@ void quat_axis_angle(float angle_deg, V3 axis, float q[4]) {
     q[0] = c; q[1] = axis.x * k; q[2] = axis.y * k; q[3] = axis.z * k;
 }
 
+bool hyperboloid_derive(const float a1[3], const float a2[3], float out[11]) {
+    V3 p1 = v3(a1[0], a1[1], a1[2]), p2 = v3(a2[0], a2[1], a2[2]);
+    float radius1 = std::sqrt(p1.x * p1.x + p1.y * p1.y), radius2 = std::sqrt(p2.x * p2.x + p2.y * p2.y);
+    float rmax = f32_max(radius1, radius2);
+    float zmin = f32_min(p1.z, p2.z), zmax = f32_max(p1.z, p2.z);
+    if (p2.z == 0.0f) { V3 t = p1; p1 = p2; p2 = t; }
+    V3 pp = p1;
+    float ah = 0.0f, ch = 0.0f;
+    bool ok = false;
+    for (int it = 0; it < 64 && !ok; ++it) {   // the reference loops until ah is finite (:42-54)
+        pp = pp + 2.0f * (p2 - p1);
+        float xy1 = pp.x * pp.x + pp.y * pp.y, xy2 = p2.x * p2.x + p2.y * p2.y;
+        ah = (1.0f / xy1 - (pp.z * pp.z) / (xy1 * p2.z * p2.z)) / (1.0f - (xy2 * pp.z * pp.z) / (xy1 * p2.z * p2.z));
+        ch = (ah * xy2 - 1.0f) / (p2.z * p2.z);
+        ok = std::isfinite(ah);
+    }
+    if (!ok) return false;
+    const float r[11] = {p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, zmin, zmax, rmax, ah, ch};
+    memcpy(out, r, sizeof r);
+    return true;
+}
+
 }  // namespace rth
 
 using namespace rth;
@@ -372,6 +394,48 @@ static int wrapper(rth_scene *s, int type, int child, const float *f, int nf) {
 int rth_add_flip_face(rth_scene *s, int child) { return wrapper(s, RTG_FLIP_FACE, child, nullptr, 0); }
 int rth_add_translate(rth_scene *s, int child, const float offset[3]) { return wrapper(s, RTG_TRANSLATE, child, offset, 3); }
 int rth_add_rotate_y(rth_scene *s, int child, float degrees) { return wrapper(s, RTG_ROTATE_Y, child, &degrees, 1); }
+
+int rth_add_transform(rth_scene *s, int child, const float obj2world[16]) {
+    if (!obj2world) { set_error("transform: null matrix"); return RT_E_INVALID; }
+    if (obj2world[12] != 0.0f || obj2world[13] != 0.0f || obj2world[14] != 0.0f || obj2world[15] != 1.0f) {
+        set_error("transform: only affine matrices (last row 0,0,0,1) are supported");
+        return RT_E_UNSUPPORTED_PRIMITIVE;
+    }
+    M4 m, inv;
+    memcpy(m.a, obj2world, sizeof m.a);
+    if (!m4_invert(m, &inv)) { set_error("transform: Matrix is not invertible"); return RT_E_INVALID; }
+    return wrapper(s, RTG_TRANSFORM, child, obj2world, 12);
+}
+
+static int quadric(rth_scene *s, int type, int mtl, const float *f, int nf) {
+    if (mtl < 0) { set_error("quadric: material %d out of range", mtl); return RT_E_INVALID; }
+    rtg_node n{};
+    n.type = type; n.material = mtl;
+    for (int i = 0; i < nf; ++i) n.f[i] = f[i];
+    return push_node(s, n, nullptr, 0);
+}
+
+int rth_add_cylinder(rth_scene *s, float radius, float z0, float z1, float phi_max, int mtl) {
+    const float f[4] = {radius, f32_min(z0, z1), f32_max(z0, z1), phi_max};
+    return quadric(s, RTG_CYLINDER, mtl, f, 4);
+}
+
+int rth_add_cone(rth_scene *s, float radius, float height, float phi_max, int mtl) {
+    const float f[3] = {radius, height, phi_max};
+    return quadric(s, RTG_CONE, mtl, f, 3);
+}
+
+int rth_add_paraboloid(rth_scene *s, float radius, float zmin, float zmax, float phi_max, int mtl) {
+    const float f[4] = {radius, f32_min(zmin, zmax), f32_max(zmin, zmax), phi_max};
+    return quadric(s, RTG_PARABOLOID, mtl, f, 4);
+}
+
+int rth_add_hyperboloid(rth_scene *s, const float p1[3], const float p2[3], float phi_max, int mtl) {
+    float d[11];
+    if (!p1 || !p2 || !hyperboloid_derive(p1, p2, d)) { set_error("hyperboloid: the implicit form has no finite coefficients"); return RT_E_INVALID; }
+    const float f[7] = {p1[0], p1[1], p1[2], p2[0], p2[1], p2[2], phi_max};
+    return quadric(s, RTG_HYPERBOLOID, mtl, f, 7);
+}
 
 int rth_add_bvh(rth_scene *s, const int32_t *children, int n) {
     if (n <= 0) { set_error("bvh: empty child list"); return RT_E_INVALID; }
@@ -619,6 +683,132 @@ int build_mesh_test(Builder &b, const rth_scene_assets *assets) {
     return rth_set_roots(s, wl, ll);
 }
 
+// types.rs:188-231 ("Graphics Gems 2, pg. 378")
+M4 random_rotation_matrix(Builder &bd) {
+    float x1 = bd.rr(), x2 = bd.rr(), x3 = bd.rr();
+    const float pi = 3.14159265358979323846f, two_pi = pi * 2.0f;
+    float z = x1, phi = two_pi * x2, r = std::sqrt(1.0f - z * z), w = pi * x3;
+    float sin_phi, cos_phi, sin_w, cos_w;
+    pm::sincosf_(phi, &sin_phi, &cos_phi);
+    pm::sincosf_(w, &sin_w, &cos_w);
+    float a = cos_w, b = sin_w * cos_phi * r, c = sin_w * sin_phi * r, d = sin_w * z;
+    M4 m = m4_identity();
+    m.at(0, 0) = 1.0f - 2.0f * (c * c + d * d); m.at(0, 1) = 2.0f * (b * c + a * d);         m.at(0, 2) = 2.0f * (b * d - a * c);
+    m.at(1, 0) = 2.0f * (b * c - a * d);        m.at(1, 1) = 1.0f - 2.0f * (b * b + d * d);  m.at(1, 2) = 2.0f * (c * d + a * b);
+    m.at(2, 0) = 2.0f * (b * d + a * c);        m.at(2, 1) = 2.0f * (c * d - a * b);         m.at(2, 2) = 1.0f - 2.0f * (b * b + c * c);
+    return m;
+}
+
+M4 rotation(float angle_deg, V3 axis) {   // quat::to_rotation_matrix(Quat::axis_angle(angle, axis))
+    float q[4];
+    quat_axis_angle(angle_deg, axis, q);
+    return quat_to_rotation_matrix(q[0], q[1], q[2], q[3]);
+}
+
+int image_tex(rth_scene *s, const rth_image &im) { return rth_add_image_texture(s, im.width, im.height, im.rgba); }
+
+// The floor, the sky light and the `lights` list shared by scene_geometric_primitives, scene_mesh and scene_blocks
+void floor_and_sky(Builder &b, int floor_tex, std::vector<int32_t> &world) {
+    rth_scene *s = b.s;
+    world.push_back(rth_add_rect(s, RTG_XZ_RECT, -1000, 1000, -1000, 1000, 0, rth_add_lambertian(s, floor_tex)));
+    world.push_back(rth_add_flip_face(s, rth_add_rect(s, RTG_XZ_RECT, -1000, 1000, -1000, 1000, 1000, b.light(1, 1, 1))));
+}
+int finish_with_sky_light(Builder &b, std::vector<int32_t> &world) {
+    rth_scene *s = b.s;
+    for (int32_t w : world) if (w < 0) return w;
+    int32_t l = rth_add_rect(s, RTG_XZ_RECT, -1000, 1000, -1000, 1000, 1000, b.light(0, 0, 0));
+    int wl = rth_add_list(s, world.data(), (int)world.size());
+    int ll = rth_add_list(s, &l, 1);
+    return rth_set_roots(s, wl, ll);
+}
+
+// main.rs:830-967
+int build_geometric_primitives(Builder &b, const rth_scene_assets *assets) {
+    rth_scene *s = b.s;
+    if (!assets) { set_error("GeometricPrimitives needs the uv-grid textures"); return RT_E_INVALID; }
+    const int grid01 = image_tex(s, assets->uvgrid01), grid03 = image_tex(s, assets->uvgrid03), grid08 = image_tex(s, assets->uvgrid08),
+              grid10 = image_tex(s, assets->uvgrid10);
+    std::vector<int32_t> world;
+    floor_and_sky(b, grid01, world);
+    const V3 ux = v3(1, 0, 0), uy = v3(0, 1, 0), uz = v3(0, 0, 1);
+    const float lo[3] = {-0.5f, -0.5f, -0.5f}, hi[3] = {0.5f, 0.5f, 0.5f};   // Block::unit_cube, block.rs:18-20
+    const float pi = 3.14159265358979323846f, two_pi = pi * 2.0f, to_rad = pi / 180.0f;
+
+    // the reference shares one Arc<Block> between the two Transforms; here each gets its own node so that
+    // every leaf has one primitive id (include/rt_scene_graph.h)
+    int block_mtl = rth_add_lambertian(s, grid03);
+    {
+        M4 r = rotation(180.0f, uy), t = m4_translate(v3(65, 65, 0)), sc = m4_scale(v3(35, 35, 35));
+        world.push_back(rth_add_transform(s, rth_add_block(s, lo, hi, block_mtl), m4_mul(m4_mul(t, r), sc).a));
+    }
+    {
+        M4 r = random_rotation_matrix(b), sc = m4_scale(v3(35, 35, 35)), t = m4_translate(v3(-65, 65, 0));
+        world.push_back(rth_add_transform(s, rth_add_block(s, lo, hi, block_mtl), m4_mul(m4_mul(t, r), sc).a));
+    }
+    {   // Cylinder::unit(None): radius 1, z in [-0.5, 0.5], full turn
+        int cyl = rth_add_cylinder(s, 1.0f, -0.5f, 0.5f, two_pi, rth_add_lambertian(s, grid01));
+        M4 r = rotation(45.0f, uy), t = m4_translate(v3(40, 30, 30)), sc = m4_scale(v3(15, 15, 65));
+        world.push_back(rth_add_transform(s, cyl, m4_mul(m4_mul(t, r), sc).a));
+    }
+    {   // partial cylinder
+        int cyl = rth_add_cylinder(s, 1.0f, -0.5f, 0.5f, pi, rth_add_lambertian(s, grid08));
+        M4 r = rotation(-45.0f, uy), t = m4_translate(v3(-40, 30, 30)), sc = m4_scale(v3(15, 15, 65));
+        world.push_back(rth_add_transform(s, cyl, m4_mul(m4_mul(t, r), sc).a));
+    }
+    int cone_mtl = rth_add_lambertian(s, grid03);
+    const M4 s25 = m4_scale(v3(25, 25, 25));
+    {
+        M4 r = rotation(90.0f, ux), t = m4_translate(v3(-25, 25, 50));
+        world.push_back(rth_add_transform(s, rth_add_cone(s, 1.0f, 1.0f, two_pi, cone_mtl), m4_mul(m4_mul(t, r), s25).a));
+    }
+    {
+        M4 r = m4_mul(rotation(-90.0f, ux), rotation(-90.0f, uz)), t = m4_translate(v3(25, 0, 50));
+        world.push_back(rth_add_transform(s, rth_add_cone(s, 1.0f, 1.0f, 330.0f * to_rad, cone_mtl), m4_mul(m4_mul(t, r), s25).a));
+    }
+    int hyp_mtl = rth_add_lambertian(s, grid10);
+    {
+        M4 r = rotation(90.0f, ux), t = m4_translate(v3(-0.0f, 25, 100));
+        world.push_back(rth_add_transform(s, rth_add_paraboloid(s, 0.5f, -0.5f, 1.0f, two_pi, hyp_mtl), m4_mul(m4_mul(t, r), s25).a));
+    }
+    {
+        M4 r = m4_mul(rotation(-120.0f, uy), rotation(90.0f, ux)), t = m4_translate(v3(-30, 25, 100));
+        world.push_back(rth_add_transform(s, rth_add_paraboloid(s, 0.5f, -0.5f, 1.0f, 300.0f * to_rad, hyp_mtl), m4_mul(m4_mul(t, r), s25).a));
+    }
+    return finish_with_sky_light(b, world);
+}
+
+// main.rs:1031-1133.  Colours: math/src/color_palette.rs material_design, through From<u32> (math/src/colors.rs:34-41)
+int build_blocks(Builder &b, const rth_scene_assets *assets) {
+    rth_scene *s = b.s;
+    if (!assets) { set_error("Blocks needs assets->uvgrid01"); return RT_E_INVALID; }
+    std::vector<int32_t> world;
+    floor_and_sky(b, image_tex(s, assets->uvgrid01), world);
+    auto checkers = [&](uint32_t odd, uint32_t even) {
+        auto tex = [&](uint32_t c) {
+            return rth_add_solid_texture(s, (float)((c >> 16) & 0xFF) / 255.0f, (float)((c >> 8) & 0xFF) / 255.0f, (float)(c & 0xFF) / 255.0f);
+        };
+        int o = tex(odd), e = tex(even);
+        return rth_add_lambertian(s, rth_add_checker_texture(s, o, e, 4.0f));
+    };
+    const uint32_t YELLOW = 0xffffeb3bu, BLACK = 0xff000000u, GREEN = 0xff4caf50u, RED = 0xfff44336u;
+    const float lo[3] = {-0.5f, -0.5f, -0.5f}, hi[3] = {0.5f, 0.5f, 0.5f};
+    const V3 uy = v3(0, 1, 0);
+    const M4 sc = m4_scale(v3(5, 10, 5));
+    {
+        M4 r = rotation(20.0f, uy), t = m4_translate(v3(-7, 5, 10));
+        world.push_back(rth_add_transform(s, rth_add_block(s, lo, hi, checkers(YELLOW, BLACK)), m4_mul(m4_mul(t, r), sc).a));
+    }
+    {
+        M4 t = m4_translate(v3(0, 5, 0));
+        world.push_back(rth_add_transform(s, rth_add_block(s, lo, hi, checkers(GREEN, BLACK)), m4_mul(t, sc).a));
+    }
+    {
+        M4 r = rotation(-20.0f, uy), t = m4_translate(v3(7, 5, 10));
+        world.push_back(rth_add_transform(s, rth_add_block(s, lo, hi, checkers(RED, BLACK)), m4_mul(m4_mul(t, r), sc).a));
+    }
+    return finish_with_sky_light(b, world);
+}
+
 }  // namespace
 
 int rth_build_scene(rth_scene *s, const char *name, uint32_t seed, const rth_scene_assets *assets) {
@@ -631,6 +821,8 @@ int rth_build_scene(rth_scene *s, const char *name, uint32_t seed, const rth_sce
     if (n == "CornellBox") return build_cornell_box(b);
     if (n == "Chapter2Final") return build_final_chapter2(b, assets, seed);
     if (n == "MeshTest") return build_mesh_test(b, assets);
+    if (n == "GeometricPrimitives") return build_geometric_primitives(b, assets);
+    if (n == "Blocks") return build_blocks(b, assets);
     set_error("scene '%s' is not covered by this backend", name);
     return RT_E_UNSUPPORTED_PRIMITIVE;
 }

@@ -83,6 +83,7 @@ struct DScene {
     const float4 *slots;
     const float4 *attrs;
     const float4 *xforms;     // 2 x float4 per record
+    const float4 *matrices;   // 9 x float4 per general Transform: world2object, obj2world, normal2world (3 rows each)
     const float4 *media;
     const float4 *lights;
     const float4 *materials;
@@ -100,8 +101,9 @@ struct DScene {
 };
 
 #define RT_N_REGIONS 24
+#define RT_STAT_WORDS (25 + RT_N_PRIM_TYPES)   // counters of one render (flush_counters); the region timers follow
 struct Counters {  // only live in the STATS instantiation
-    uint32_t rays, node_visits, prim_tests[6], medium_tests, light_pdf_evals, shades[5], tex_evals[4], accepted;
+    uint32_t rays, node_visits, prim_tests[RT_N_PRIM_TYPES], medium_tests, light_pdf_evals, shades[5], tex_evals[4], accepted;
     uint32_t phase_lanes[5], phase_slots[5];
     uint32_t region[RT_N_REGIONS];   // cycles a wave spent in a code region (counted on its first active lane)
 };
@@ -140,11 +142,24 @@ struct Rec {      // HitRecord (hittable.rs:6-14)
 
 /* ------------------------------------------------------------------ primitive tests */
 
-// Ray into the frame of a wrapped primitive: Translate (transform.rs:34) then RotateY (:117-126).
-RT_DEV Ray to_object_rec(float4 a, float4 b, const Ray &r) {
+// Mat4 x Vec4 (math/src/mat4.rs:434-441), rows 0..2: a*x + b*y + c*z + d*w, summed left to right (w is 0 or 1)
+RT_DEV float mat_row(float4 m, V3 v, float w) { return m.x * v.x + m.y * v.y + m.z * v.z + m.w * w; }
+RT_DEV V3 mat_apply(const float4 *m, V3 v, float w) { return v3(mat_row(m[0], v, w), mat_row(m[1], v, w), mat_row(m[2], v, w)); }
+
+// Ray into the frame of a wrapped primitive: Translate (transform.rs:34) then RotateY (:117-126), or a general
+// Transform (transform.rs:190 + math/src/ray.rs:42-54).  EXT = false leaves the general Transform out: slots
+// under one are never reached through the BVH (rt_api.h), so the traversal kernel does not carry the code.
+template <bool EXT = true>
+RT_DEV Ray to_object_rec(const DScene &sc, float4 a, float4 b, const Ray &r) {
     int flags = f2i(a.x);
     float sin_t = a.y, cos_t = a.z;
     Ray q = r;
+    if (EXT && (flags & 4)) {
+        const float4 *m = sc.matrices + 9 * (size_t)f2i(a.y);
+        q.o = mat_apply(m, r.o, 1.0f);
+        q.d = mat_apply(m, r.d, 0.0f);
+        return q;
+    }
     if (flags & 2) q.o = r.o - v3(a.w, b.x, b.y);
     if (flags & 1) {
         V3 o = q.o, d = q.d;
@@ -155,7 +170,8 @@ RT_DEV Ray to_object_rec(float4 a, float4 b, const Ray &r) {
     }
     return q;
 }
-RT_DEV Ray to_object(const DScene &sc, int xf, const Ray &r) { return to_object_rec(sc.xforms[2 * xf], sc.xforms[2 * xf + 1], r); }
+template <bool EXT = true>
+RT_DEV Ray to_object(const DScene &sc, int xf, const Ray &r) { return to_object_rec<EXT>(sc, sc.xforms[2 * xf], sc.xforms[2 * xf + 1], r); }
 
 // A slot as the kernels read it: all 64 bytes at once, so that the loads of a test do not wait on
 // each other.  In the DEVICE copy of the slot array, spheres and rectangles under a transform carry
@@ -170,7 +186,7 @@ RT_DEV SlotRec load_slot(const DScene &sc, uint32_t slot) {
     s.q0 = p[0]; s.meta = p[1]; s.q2 = p[2]; s.q3 = p[3];
     return s;
 }
-RT_DEV bool type_has_inline_xform(int type) { return type != RT_PRIM_MOVING_SPHERE && type != RT_PRIM_TRIANGLE; }
+__host__ __device__ inline bool type_has_inline_xform(int type) { return type != RT_PRIM_MOVING_SPHERE && type != RT_PRIM_TRIANGLE && type != RT_PRIM_HYPERBOLOID; }
 
 RT_DEV bool sphere_roots(V3 center, float radius, const Ray &r, float t_min, float t_max, float *t_out) {  // sphere.rs:45-66
     V3 oc = r.o - center;
@@ -240,8 +256,140 @@ RT_DEV bool tri_test(const DScene &sc, uint32_t slot, float4 q0, float p3z, floa
     return true;
 }
 
+/* ---- quadrics (cylinder.rs, cone.rs, paraboloid.rs, hyperboloid.rs; "Physically based rendering" 3.4-3.5) ---- */
+
+// math/src/polynomial.rs:11-39.  roots start as the caller's [0, 0]; the linear case writes one of them.
+RT_DEV uint32_t poly_quadratic(float a, float b, float c, float *r0, float *r1) {
+    *r0 = 0.0f; *r1 = 0.0f;
+    if (a == 0.0f) {                       // poly_linear(b, c)
+        if (b == 0.0f) return 0u;
+        *r0 = -c / b;
+        return 1u;
+    }
+    float delta = b * b - 4.0f * a * c;
+    if (delta == 0.0f) {                   // sic: (-b / 2) * a
+        *r0 = -b / 2.0f * a;
+        *r1 = -b / 2.0f * a;
+        return 2u;
+    }
+    if (!(delta < 0.0f)) {   // is_sign_positive; a NaN delta counts as positive whatever its sign bit
+        float sgn = b != b ? b : copysignf(1.0f, b);   // f32::signum
+        float q = -(b + sgn * sqrtf(delta)) / 2.0f;
+        float x0 = q / a, x1 = c / q;
+        if (x0 > x1) { float t = x0; x0 = x1; x1 = t; }
+        *r0 = x0; *r1 = x1;
+        return 2u;
+    }
+    return 0u;
+}
+
+struct QuadHit {
+    float t, phi, v;
+    V3 p;
+};
+
+// The hit tests of the four quadrics share their shape: roots, pick one, clip against z / phi, try the other.
+// Cone, paraboloid and hyperboloid ignore t_min and accept any t > 0 (cone.rs:61-65, paraboloid.rs:78-88).
+RT_DEV bool quadric_test(int type, const SlotRec &s, const Ray &r, float t_min, float t_max, QuadHit *h) {
+    const float two_pi = 3.14159265358979323846f * 2.0f;
+    const V3 o = r.o, d = r.d;
+    const float4 q0 = s.q0;
+    float a, b, c, zlo, zhi, phi_max = q0.w;
+    V3 p1 = v3(0.0f, 0.0f, 0.0f), p2 = p1;
+    if (type == RT_PRIM_CYLINDER) {            // cylinder.rs:55-57
+        a = d.x * d.x + d.y * d.y;
+        b = 2.0f * (d.x * o.x + d.y * o.y);
+        c = o.x * o.x + o.y * o.y - q0.x * q0.x;
+        zlo = q0.y; zhi = q0.z;
+    } else if (type == RT_PRIM_CONE) {         // cone.rs:43-52
+        float k = q0.x / q0.y;
+        k = k * k;
+        a = d.x * d.x + d.y * d.y - k * d.z * d.z;
+        b = 2.0f * (d.x * o.x + d.y * o.y - k * d.z * (o.z - q0.y));
+        c = o.x * o.x + o.y * o.y - k * (o.z - q0.y) * (o.z - q0.y);
+        zlo = 0.0f; zhi = q0.y;
+    } else if (type == RT_PRIM_PARABOLOID) {   // paraboloid.rs:59-63
+        float k = q0.z / (q0.x * q0.x);
+        a = k * (d.x * d.x + d.y * d.y);
+        b = 2.0f * k * (d.x * o.x + d.y * o.y) - d.z;
+        c = k * (o.x * o.x + o.y * o.y) - o.z;
+        zlo = q0.y; zhi = q0.z;
+    } else {                                   // hyperboloid.rs:84-86
+        float ah = s.q3.x, ch = s.q3.y;
+        a = ah * d.x * d.x + ah * d.y * d.y - ch * d.z * d.z;
+        b = 2.0f * (ah * d.x * o.x + ah * d.y * o.y - ch * d.z * o.z);
+        c = ah * o.x * o.x + ah * o.y * o.y - ch * o.z * o.z - 1.0f;
+        zlo = s.meta.w; zhi = s.q2.w;
+        p1 = v3(q0.x, q0.y, q0.z); p2 = v3(s.q2.x, s.q2.y, s.q2.z);
+    }
+    float t0, t1;
+    if (poly_quadratic(a, b, c, &t0, &t1) == 0u) return false;
+    float thit;
+    if (type == RT_PRIM_CYLINDER) {            // cylinder.rs:68-76
+        if (t0 > t_max || t1 < t_min) return false;
+        thit = t0 < t_min ? t1 : t0;
+        if (thit > t_max) return false;
+    } else {                                   // cone.rs:61-68 = paraboloid.rs:78-88 = hyperboloid.rs:97-107
+        if (t0 > t_max || t1 <= 0.0f) return false;
+        thit = t0 <= 0.0f ? t1 : t0;
+        if (thit > t_max) return false;
+    }
+    V3 p;
+    float phi, v = 0.0f;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        p = r.at(thit);
+        if (type == RT_PRIM_HYPERBOLOID) {     // hyperboloid.rs:111-117, 133-139
+            v = (p.z - p1.z) / (p2.z - p1.z);
+            V3 pr = (1.0f - v) * p1 + v * p2;
+            phi = pm::atan2f_(pr.x * p.y - p.x * pr.y, p.x * pr.x + p.y * pr.y);
+            if (phi < 0.0f) phi += pass == 0 ? 2.0f : two_pi;   // sic: the first attempt adds 2, not 2 pi (:116)
+        } else {
+            phi = pm::atan2f_(p.y, p.x);
+            if (phi < 0.0f) phi = phi + two_pi;
+        }
+        if (!(p.z < zlo || p.z > zhi || phi > phi_max)) break;   // inside the clipping parameters
+        if (pass == 1 || thit == t1) return false;
+        thit = t1;
+        if (t1 > t_max) return false;
+    }
+    h->t = thit; h->phi = phi; h->v = v; h->p = p;
+    return true;
+}
+
+// u, v and the outward normal of an accepted quadric hit (cylinder.rs:112-121, cone.rs:104-114,
+// paraboloid.rs:123-137, hyperboloid.rs:148-162)
+RT_DEV V3 quadric_record(int type, const SlotRec &s, const QuadHit &h, float *u, float *v) {
+    const float4 q0 = s.q0;
+    const float phi_max = q0.w;
+    const V3 p = h.p;
+    *u = h.phi / phi_max;
+    V3 dpdu = v3(-phi_max * p.y, phi_max * p.x, 0.0f), dpdv;
+    if (type == RT_PRIM_CYLINDER) {
+        *v = (p.z - q0.y) / (q0.z - q0.y);
+        dpdv = v3(0.0f, 0.0f, q0.z - q0.y);
+        return normalize(cross(dpdv, dpdu));
+    }
+    if (type == RT_PRIM_CONE) {
+        *v = p.z / q0.y;
+        dpdu = v3(-phi_max * p.y, phi_max * p.y, 0.0f);   // sic: p.y twice (cone.rs:109)
+        dpdv = v3(-p.x / (1.0f - *v), -p.y / (1.0f - *v), q0.y);
+    } else if (type == RT_PRIM_PARABOLOID) {
+        *v = (p.z - q0.y) / (q0.z - q0.y);
+        dpdv = (q0.z - q0.y) * v3(p.x / (2.0f * p.z), p.y / (2.0f * p.z), 1.0f);
+    } else {
+        *v = h.v;
+        const V3 p1 = v3(q0.x, q0.y, q0.z), p2 = v3(s.q2.x, s.q2.y, s.q2.z);
+        float sin_phi, cos_phi;
+        pm::sincosf_(h.phi, &sin_phi, &cos_phi);
+        dpdv = v3((p2.x - p1.x) * cos_phi - (p2.y - p1.y) * sin_phi, (p2.x - p1.x) * sin_phi + (p2.y - p1.y) * cos_phi, p2.z - p1.z);
+    }
+    return normalize(cross(dpdu, dpdv));
+}
+
 // Hit test of one slot: true + t when `obj.hit(r, t_min, t_max)` of that leaf would return Some.
-template <bool STATS>
+// EXT = false: without the quadrics and the general Transform (see to_object_rec).
+template <bool STATS, bool EXT = true>
 RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, const Ray &r_world, float t_min, float t_max, float *t_out,
                          int32_t *id_out, Counters &cnt) {
     const float4 q0 = s.q0, meta = s.meta;
@@ -251,7 +399,13 @@ RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, cons
     *id_out = f2i(meta.z);
     if (STATS) cnt.prim_tests[type] += 1;
     Ray r = r_world;
-    if (xf >= 0) r = type_has_inline_xform(type) ? to_object_rec(s.q2, s.q3, r_world) : to_object(sc, xf, r_world);
+    if (xf >= 0) r = type_has_inline_xform(type) ? to_object_rec<EXT>(sc, s.q2, s.q3, r_world) : to_object<EXT>(sc, xf, r_world);
+    if (EXT && type >= RT_PRIM_CYLINDER) {
+        QuadHit qh;
+        if (!quadric_test(type, s, r, t_min, t_max, &qh)) return false;
+        *t_out = qh.t;
+        return true;
+    }
     float a, b;
     switch (type) {
     case RT_PRIM_SPHERE: case RT_PRIM_MOVING_SPHERE: {   // one sphere_roots for both kinds: only the centre differs
@@ -269,10 +423,10 @@ RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, cons
     }
     }
 }
-template <bool STATS>
+template <bool STATS, bool EXT = true>
 RT_DEV bool slot_hit(const DScene &sc, uint32_t slot, const Ray &r_world, float t_min, float t_max, float *t_out, int32_t *id_out,
                      Counters &cnt) {
-    return slot_hit_rec<STATS>(sc, slot, load_slot(sc, slot), r_world, t_min, t_max, t_out, id_out, cnt);
+    return slot_hit_rec<STATS, EXT>(sc, slot, load_slot(sc, slot), r_world, t_min, t_max, t_out, id_out, cnt);
 }
 
 RT_DEV void sphere_uv(V3 p, float *u, float *v) {  // sphere.rs:25-41
@@ -283,8 +437,9 @@ RT_DEV void sphere_uv(V3 p, float *u, float *v) {  // sphere.rs:25-41
 }
 
 // Full HitRecord of a slot for a known t: the same arithmetic as the leaf's hit() followed by
-// the wrappers on the way out (RotateY transform.rs:128-143, Translate :35-44, FlipFace).
-RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, float t, bool want_uv) {
+// the wrappers on the way out (RotateY transform.rs:128-143, Translate :35-44, Transform :192-203, FlipFace).
+// t_min / t_max: the bounds the accepted test ran with (a quadric repeats its test to know which root it took).
+RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, float t, bool want_uv, float t_min, float t_max) {
     const SlotRec s = load_slot(sc, slot);
     float4 q0 = s.q0, meta = s.meta;
     int w4 = f2i(meta.x);
@@ -295,12 +450,18 @@ RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, floa
         if (type_has_inline_xform(type)) { xa = s.q2; xb = s.q3; }
         else { xa = sc.xforms[2 * xf]; xb = sc.xforms[2 * xf + 1]; }
     }
-    Ray r = xf >= 0 ? to_object_rec(xa, xb, r_world) : r_world;
+    Ray r = xf >= 0 ? to_object_rec(sc, xa, xb, r_world) : r_world;
     Rec rec;
     rec.t = t;
     rec.material = f2i(meta.y);
     rec.u = 0.0f; rec.v = 0.0f;
     V3 p = r.at(t), n;
+    if (type >= RT_PRIM_CYLINDER) {
+        QuadHit qh;
+        quadric_test(type, s, r, t_min, t_max, &qh);   // same arithmetic as the accepted test
+        p = qh.p;
+        n = quadric_record(type, s, qh, &rec.u, &rec.v);
+    } else
     switch (type) {
     case RT_PRIM_SPHERE: case RT_PRIM_MOVING_SPHERE: {
         V3 c = v3(q0.x, q0.y, q0.z);
@@ -334,6 +495,11 @@ RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, floa
     V3 nn = front ? n : -n;
     if (xf >= 0) {
         int flags = f2i(xa.x);
+        if (flags & 4) {   // transform.rs:195-201: p and normal to world space, front_face / t / u / v kept
+            const float4 *m = sc.matrices + 9 * (size_t)f2i(xa.y);
+            p = mat_apply(m + 3, p, 1.0f);
+            nn = normalize(mat_apply(m + 6, nn, 0.0f));
+        }
         if (flags & 1) {
             float sin_t = xa.y, cos_t = xa.z;
             V3 p0 = p, n0 = nn;
@@ -463,7 +629,7 @@ RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_
         for (uint32_t i = 0; i < count; ++i) {
             float t;
             int32_t id;
-            if (slot_hit<STATS>(sc, first + i, r, t_min, best.t, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)(first + i));
+            if (slot_hit<STATS, false>(sc, first + i, r, t_min, best.t, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)(first + i));
         }
         ref = pop_ref(stack, sp);
     }
@@ -677,7 +843,7 @@ RT_DEV void trav_leaf_step(const DScene &sc, const Ray &r, float t_min, Trav &tv
     for (uint32_t i = 0; i < count; ++i) {
         float t;
         int32_t id;
-        if (slot_hit<STATS>(sc, first + i, r, t_min, tv.best.t, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)(first + i));
+        if (slot_hit<STATS, false>(sc, first + i, r, t_min, tv.best.t, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)(first + i));
     }
     tv.ref = pop_ref(stack, tv.sp);
 }
@@ -950,7 +1116,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
         int tkind = f2i(sc.materials[2 * mat + 1].w);   // 0 untextured, kind + 1 otherwise
         bool want_uv = tkind > RTG_TEX_SOLID + 1 && texture_needs_uv(sc, f2i(ma.y));
         RG_BEGIN(RG_RECORD);
-        rec = slot_record(sc, (uint32_t)best.slot, ps.ray, best.t, want_uv);
+        rec = slot_record(sc, (uint32_t)best.slot, ps.ray, best.t, want_uv, 0.001f, INFINITY);
         RG_END(RG_RECORD);
     }
     float4 ma = sc.materials[2 * rec.material], mb = sc.materials[2 * rec.material + 1];
@@ -1143,7 +1309,7 @@ __global__ void __launch_bounds__(256) first_hit_kernel(DScene sc, const float *
     const Stack stack{lds_stack + threadIdx.x, blockDim.x, 0xffffffffu, nullptr, 0u};   // launched with the full BVH depth in LDS
     bool h = closest_hit<false>(sc, r, t_min, t_max, false, rng, best, stack, cnt);
     Rec rec{};
-    if (h) rec = slot_record(sc, (uint32_t)best.slot, r, best.t, true);
+    if (h) rec = slot_record(sc, (uint32_t)best.slot, r, best.t, true, t_min, t_max);
     prim_id[i] = h ? (uint32_t)best.id : RT_MISS;
     t_out[i] = h ? rec.t : 0.0f;
     normal3[3 * i] = h ? rec.normal.x : 0.0f; normal3[3 * i + 1] = h ? rec.normal.y : 0.0f; normal3[3 * i + 2] = h ? rec.normal.z : 0.0f;

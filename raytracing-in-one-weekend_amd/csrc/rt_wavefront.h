@@ -116,20 +116,21 @@ RT_DEV void flush_counters(const Counters &cnt, uint32_t paths, unsigned long lo
     if (kTimers && !STATS) {
         for (int i = 0; i < RT_N_REGIONS; ++i) {
             uint32_t w = wave_sum(cnt.region[i]);
-            if ((threadIdx.x & 63u) == 0 && w) atomicAdd(&stats[32 + i], (unsigned long long)w);
+            if ((threadIdx.x & 63u) == 0 && w) atomicAdd(&stats[RT_STAT_WORDS + 1 + i], (unsigned long long)w);
         }
     }
     if (!STATS) return;
-    uint32_t vals[31];
+    uint32_t vals[RT_STAT_WORDS];   // the order rt_render copies into rt_stats
+    constexpr int P = RT_N_PRIM_TYPES;
     vals[0] = paths;
     vals[1] = cnt.rays; vals[2] = cnt.node_visits;
-    for (int i = 0; i < 6; ++i) vals[3 + i] = cnt.prim_tests[i];
-    vals[9] = cnt.medium_tests; vals[10] = cnt.light_pdf_evals;
-    for (int i = 0; i < 5; ++i) vals[11 + i] = cnt.shades[i];
-    for (int i = 0; i < 4; ++i) vals[16 + i] = cnt.tex_evals[i];
-    vals[20] = cnt.accepted;
-    for (int i = 0; i < 5; ++i) { vals[21 + i] = cnt.phase_lanes[i]; vals[26 + i] = cnt.phase_slots[i]; }
-    for (int i = 0; i < 31; ++i) {
+    for (int i = 0; i < P; ++i) vals[3 + i] = cnt.prim_tests[i];
+    vals[3 + P] = cnt.medium_tests; vals[4 + P] = cnt.light_pdf_evals;
+    for (int i = 0; i < 5; ++i) vals[5 + P + i] = cnt.shades[i];
+    for (int i = 0; i < 4; ++i) vals[10 + P + i] = cnt.tex_evals[i];
+    vals[14 + P] = cnt.accepted;
+    for (int i = 0; i < 5; ++i) { vals[15 + P + i] = cnt.phase_lanes[i]; vals[20 + P + i] = cnt.phase_slots[i]; }
+    for (int i = 0; i < RT_STAT_WORDS; ++i) {
         uint32_t w = wave_sum(vals[i]);
         if ((threadIdx.x & 63u) == 0 && w) atomicAdd(&stats[i], (unsigned long long)w);
     }

@@ -155,13 +155,14 @@ def load_image_rgba(path):
 
 
 class Assets:
-    """Files the reference's scene builders open by path (main.rs:778, 975, 1001, 1012)."""
+    """Files the reference's scene builders open by path (main.rs:778, 836-925, 975, 1001, 1012, 1037)."""
 
     def __init__(self, data_dir=DATA_DIR, mesh_grid=1, need=("earthmap", "uvgrid01", "uvgrid09", "teapot")):
         self.c = _ffi.rth_scene_assets()
         self._keep = []
         files = {"earthmap": "textures/misc/earthmap.jpg", "uvgrid01": "textures/uv_grids/ash_uvgrid01.jpg",
-                 "uvgrid09": "textures/uv_grids/ash_uvgrid09.jpg"}
+                 "uvgrid09": "textures/uv_grids/ash_uvgrid09.jpg", "uvgrid03": "textures/uv_grids/ash_uvgrid03.jpg",
+                 "uvgrid08": "textures/uv_grids/ash_uvgrid08.jpg", "uvgrid10": "textures/uv_grids/ash_uvgrid10.jpg"}
         for k, rel in files.items():
             if k not in need:
                 continue
@@ -202,7 +203,7 @@ class FlatScene:
 class Scene:
     """A `(world, lights)` pair as returned by the reference's scene_*() functions."""
 
-    SUPPORTED = ("RandomWorld", "CornellBox", "Chapter2Final", "MeshTest")
+    SUPPORTED = ("RandomWorld", "CornellBox", "Chapter2Final", "MeshTest", "GeometricPrimitives", "Blocks")
 
     def __init__(self):
         self._h = C.c_void_p(_ffi.host_lib().rth_scene_new())
@@ -245,6 +246,16 @@ class Scene:
     def flip_face(self, child): return _check(_ffi.host_lib().rth_add_flip_face(self._h, child))
     def translate(self, child, offset): return _check(_ffi.host_lib().rth_add_translate(self._h, child, _f3(offset)))
     def rotate_y(self, child, degrees): return _check(_ffi.host_lib().rth_add_rotate_y(self._h, child, degrees))
+    def transform(self, child, obj2world):
+        """Transform::new(obj2world, child) (transform.rs:162-175); obj2world = 4x4 row-major, affine."""
+        m = (C.c_float * 16)(*[float(x) for x in np.asarray(obj2world, np.float32).reshape(16)])
+        return _check(_ffi.host_lib().rth_add_transform(self._h, child, m))
+
+    def cylinder(self, radius, z0, z1, phi_max, mtl): return _check(_ffi.host_lib().rth_add_cylinder(self._h, radius, z0, z1, phi_max, mtl))
+    def cone(self, radius, height, phi_max, mtl): return _check(_ffi.host_lib().rth_add_cone(self._h, radius, height, phi_max, mtl))
+    def paraboloid(self, radius, zmin, zmax, phi_max, mtl): return _check(_ffi.host_lib().rth_add_paraboloid(self._h, radius, zmin, zmax, phi_max, mtl))
+    def hyperboloid(self, p1, p2, phi_max, mtl): return _check(_ffi.host_lib().rth_add_hyperboloid(self._h, _f3(p1), _f3(p2), phi_max, mtl))
+
     def constant_medium(self, boundary, tex, density): return _check(_ffi.host_lib().rth_add_constant_medium(self._h, boundary, tex, density))
 
     def _ids(self, children):

@@ -51,6 +51,7 @@ def lib():
         L.orc_math.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_int32]; L.orc_math.restype = C.c_float
         L.orc_lights_pdf_value.argtypes = [vp, C.c_float * 3, C.c_float * 3]; L.orc_lights_pdf_value.restype = C.c_float
         L.orc_perlin.argtypes = [C.c_void_p, C.c_float * 3, C.c_int32]; L.orc_perlin.restype = C.c_float
+        L.orc_set_trace.argtypes = [C.c_int32]; L.orc_set_trace.restype = None
         _lib = L
     return _lib
 

@@ -79,7 +79,7 @@ def compare_images(rt, gpu, oracle, params, camera, sampler, **kw):
 
 
 @pytest.mark.parametrize("name,width,spp,n_rays", [("C1", 240, 9, 1 << 16), ("C2", 96, 16, 1 << 16), ("C3", 96, 16, 1 << 16),
-                                                   ("C4", 64, 4, 1 << 13)])
+                                                   ("C4", 64, 4, 1 << 13), ("GP", 96, 16, 1 << 16), ("BLOCKS", 96, 16, 1 << 16)])
 def test_image_and_first_hit_small(rt, gpu, name, width, spp, n_rays):
     extra = {"mesh_grid": 1} if name == "C4" else {}
     scene, params, camera, sampler = rt.configs.build(name, image_width=width, samples_per_pixel=spp, **extra)
@@ -163,3 +163,68 @@ def test_other_projections_match_the_oracle(rt, gpu, projection, name):
     assert np.all(got[..., 3] == sampler.spp)
     if projection == 2:      # FishEye: the corners of the frame are outside the unit disk and trace nothing
         assert rays[0, 0] == 0 and rays[-1, -1] == 0 and rays[rays.shape[0] // 2, rays.shape[1] // 2] > 0
+
+
+def quadric_playground(rt):
+    """Every quadric kind, partial sweeps, FlipFace on either side of a Transform, metal and glass quadrics (so that
+    paths leave the surfaces at grazing angles) next to 31 spheres that go through the BVH."""
+    two_pi = float(np.float32(np.pi) * np.float32(2))
+    rng = np.random.default_rng(5)
+    s = rt.host.Scene()
+    grey = s.lambertian(s.checker(s.solid(0.2, 0.3, 0.1), s.solid(0.9, 0.9, 0.9), 4.0))
+    metal = s.metal(0.8, 0.8, 0.9, 0.1)
+    glass = s.dielectric(1.5)
+    # the floor is a rectangle, as in the reference's scenes with these primitives (main.rs:839-848): paths that get under
+    # a r = 1000 ground SPHERE run into the f32 cancellation false-positives of DESIGN.md §3
+    objs = [s.xz_rect(-1000, 1000, -1000, 1000, 0, grey)]
+    for i in range(30):
+        c = rng.uniform(-6, 6, 3).astype(np.float32)
+        objs.append(s.sphere((float(c[0]), 0.3, float(c[2])), 0.3, s.lambertian(s.solid(*rng.uniform(0.2, 0.9, 3).tolist()))))
+
+    def trs(t, angle, axis, scale):
+        a = np.radians(angle)
+        c, si = np.cos(a), np.sin(a)
+        x, y, z = axis
+        r = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * si, x * z * (1 - c) + y * si, 0],
+                      [y * x * (1 - c) + z * si, c + y * y * (1 - c), y * z * (1 - c) - x * si, 0],
+                      [z * x * (1 - c) - y * si, z * y * (1 - c) + x * si, c + z * z * (1 - c), 0], [0, 0, 0, 1]])
+        m = np.eye(4); m[:3, 3] = t
+        return (m @ r @ np.diag(list(scale) + [1.0])).astype(np.float32)
+
+    objs.append(s.transform(s.cylinder(1, -0.5, 0.5, two_pi, metal), trs((-3, 1.5, 0), 90, (1, 0, 0), (0.8, 0.8, 3))))
+    objs.append(s.transform(s.cylinder(1, -0.5, 0.5, 4.0, grey), trs((3, 1.0, 1), 70, (0, 1, 0), (1, 1, 2))))
+    objs.append(s.transform(s.cone(1, 1, two_pi, grey), trs((-1.5, 0, -4), -90, (1, 0, 0), (1.5, 1.5, 2.5))))
+    objs.append(s.transform(s.cone(1, 1, 5.0, glass), trs((2, 0, -3), -90, (1, 0, 0), (1, 1, 2))))
+    objs.append(s.transform(s.paraboloid(0.5, -0.5, 1.0, two_pi, metal), trs((-2, 2.0, -3), 90, (1, 0, 0), (2, 2, 2))))
+    objs.append(s.transform(s.hyperboloid((1, 0, -1), (0.6, 0.5, 1), 5.5, grey), trs((5, 1.2, -1), 90, (1, 0, 0), (1, 1, 1.2))))
+    objs.append(s.paraboloid(1.0, 0.0, 1.0, two_pi, grey))                                     # a quadric with no Transform at all
+    objs.append(s.transform(s.block((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), grey), trs((-5, 0.8, 2), 30, (0, 1, 0), (1, 1.6, 1))))
+    objs.append(s.flip_face(s.transform(s.xz_rect(-1, 1, -1, 1, 0, s.diffuse_light(s.solid(6, 6, 6))), trs((0, 6, 0), 0, (0, 1, 0), (3, 1, 3)))))
+    objs.append(s.transform(s.flip_face(s.sphere((0, 0, 0), 1, glass)), trs((1, 0.7, 5), 0, (0, 1, 0), (0.7, 0.7, 0.7))))
+    light = s.xz_rect(-3, 3, -3, 3, 6, s.diffuse_light(s.solid(0, 0, 0)))
+    s.set_roots(s.hittable_list(objs), s.hittable_list([light]))
+    params = rt.host.RaytracerConfig.load().scene_params("CornellBox").replace(
+        image_width=128, aspect_ratio=1.6, samples_per_pixel=16, look_from=(0.0, 4.0, 13.0), look_at=(0.0, 1.0, 0.0),
+        vertical_fov=40.0, background=(0.3, 0.4, 0.6))
+    return s, params
+
+
+def test_quadrics_and_transforms_next_to_a_bvh(rt, gpu):
+    """Quadrics and slots under a general Transform live in the always-list (they may accept t < t_min, cone.rs:61-65)
+    while everything else goes through the BVH."""
+    s, params = quadric_playground(rt)
+    flat = s.flatten()
+    assert flat.desc.n_bvh_nodes > 0 and flat.desc.always_count == 7 + 6 + 1 + 1
+    camera = params.camera()
+    sampler = rt.host.MultiJitteredSampler(16)
+    gpu.upload_scene(flat)
+    gpu.upload_sampler(sampler)
+    oracle = O.OracleScene(s)
+    rays = primary_and_bounce_rays(rt, s, params, camera, 1 << 15)
+    g, exact = check_first_hit(gpu, oracle, rays)
+    assert exact
+    hit = g[0] != 0xFFFFFFFF
+    quadric_ids = set(range(31, 38))
+    assert len(quadric_ids & set(g[0][hit].tolist())) == 7, "every quadric must be seen by some ray"
+    check_first_hit(gpu, oracle, bounce_rays(rays, g[1], g[2], hit))
+    compare_images(rt, gpu, oracle, params, camera, sampler)

@@ -136,7 +136,29 @@ def test_scene_builders_object_counts(rt):
     assert f.desc.n_slots == f.desc.n_prims - 2 and f.desc.n_media == 2 and f.desc.n_perlin == 1
     assert f.desc.n_texel_bytes == 1024 * 512 * 4
     with pytest.raises(rt.RtError):
-        rt.host.Scene.build("Blocks")
+        rt.host.Scene.build("PerlinSpheres")                      # a Scene variant nobody asked for yet
+
+    s = rt.host.Scene.build("Blocks", assets=rt.host.Assets(need=("uvgrid01",)))
+    g, types = graph_counts(s)
+    assert g.nodes[g.world_root].child_count == 5 and types.count(13) == 3      # main.rs:1049-1120: floor, light, 3 Transform(Block)
+    f = s.flatten()
+    assert f.desc.n_prims == 2 + 3 * 6 and f.desc.n_matrices == 3 and f.desc.always_count == f.desc.n_slots
+    m = np.ctypeslib.as_array(f.desc.matrices, (3, 3, 3, 4)).astype(np.float64)  # [transform][w2o, o2w, n2w][row][col]
+    for w2o, o2w, n2w in m:
+        full = lambda a: np.vstack([a, [0, 0, 0, 1]])
+        assert np.allclose(full(w2o) @ full(o2w), np.eye(4), atol=1e-5)          # transform.rs:166
+        assert np.allclose(n2w[:, :3], np.linalg.inv(w2o[:, :3]).T * np.linalg.det(w2o[:, :3]), rtol=1e-4, atol=1e-7)  # adjoint^T (:171)
+    # block1 = translate(0,5,0) * scale(5,10,5), main.rs:1093-1095
+    assert np.allclose(m[1, 1], [[5, 0, 0, 0], [0, 10, 0, 5], [0, 0, 5, 0]])
+
+    s = rt.host.Scene.build("GeometricPrimitives", assets=rt.host.Assets(need=("uvgrid01", "uvgrid03", "uvgrid08", "uvgrid10")))
+    g, types = graph_counts(s)
+    assert g.nodes[g.world_root].child_count == 10                # main.rs:848-954
+    assert [types.count(t) for t in (13, 14, 15, 16, 5)] == [8, 2, 2, 2, 2]
+    f = s.flatten()
+    assert f.desc.n_prims == 2 + 2 * 6 + 6 and f.desc.n_matrices == 8
+    types4 = f.slots()[:, 4].view(np.int32) & 15
+    assert sorted(types4[types4 >= 6].tolist()) == [6, 6, 7, 7, 8, 8]
 
 
 def check_bvh(flat, expect_boxes=False):
@@ -199,7 +221,8 @@ def check_bvh(flat, expect_boxes=False):
     walk(d.bvh_root_ref, 0)
     if expect_boxes:
         assert checked[0] > 100
-    assert (seen == 1).all(), "every slot must sit in exactly one leaf"
+    seen[d.always_begin:d.always_begin + d.always_count] += 1     # the always-list is tested for every ray instead
+    assert (seen == 1).all(), "every slot must sit in exactly one leaf or in the always-list"
     assert 3 * max_depth[0] + 1 <= d.bvh_stack_depth             # a visit pushes at most three children
     ids = slots[:, 6].view(np.int32)
     assert len(set(ids.tolist())) == d.n_slots
@@ -216,6 +239,26 @@ def test_flatten_bvh_invariants(rt):
     assert ((w4 & 16) != 0).sum() == 1                            # one FlipFace'd light
 
 
+def test_quadrics_and_transformed_slots_stay_out_of_the_bvh(rt):
+    # cone / paraboloid / hyperboloid accept hits below t_min (cone.rs:61-65): they are tested for every ray
+    s = rt.host.Scene()
+    m = s.lambertian(s.solid(1, 1, 1))
+    objs = [s.sphere((3.0 * i, 0, 0), 1, m) for i in range(40)]
+    objs.append(s.cone(1, 1, 6.0, m))
+    objs.append(s.hyperboloid((1, 0, -1), (1, 0, 1), 6.0, m))
+    objs.append(s.transform(s.flip_face(s.sphere((0, 0, 0), 1, m)), np.diag([2.0, 2.0, 2.0, 1.0])))
+    s.set_roots(s.hittable_list(objs), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
+    f = s.flatten()
+    d = f.desc
+    assert d.n_slots == 43 and d.always_begin == 40 and d.always_count == 3 and d.n_bvh_nodes > 0
+    check_bvh(f)
+    sl = f.slots()
+    assert (sl[40:, 4].view(np.int32) & 15).tolist() == [7, 9, 0]
+    assert sl[40:, 6].view(np.int32).tolist() == [40, 41, 42]      # primitive ids follow the world list
+    assert (sl[42, 4].view(np.int32) & 16) != 0                    # FlipFace inside a Transform survives (transform.rs:198-202)
+    assert np.allclose(sl[41, 12:14], [1.0, 0.0])                  # x^2 + y^2 - 0 z^2 = 1: ah = 1, ch = 0
+
+
 def test_unsupported_nesting_is_reported(rt):
     s = rt.host.Scene()
     m = s.lambertian(s.solid(1, 1, 1))
@@ -224,6 +267,16 @@ def test_unsupported_nesting_is_reported(rt):
     with pytest.raises(rt.RtError) as e:
         s.flatten()
     assert e.value.status == -5
+    s = rt.host.Scene()
+    m = s.lambertian(s.solid(1, 1, 1))
+    with pytest.raises(rt.RtError):                                # not affine
+        s.transform(s.sphere((0, 0, 0), 1, m), np.arange(16.0))
+    with pytest.raises(rt.RtError):                                # singular: the reference asserts (mat4.rs:610)
+        s.transform(s.sphere((0, 0, 0), 1, m), np.diag([1.0, 0.0, 1.0, 1.0]))
+    nested = s.transform(s.translate(s.sphere((0, 0, 0), 1, m), (1, 0, 0)), np.eye(4))
+    s.set_roots(s.hittable_list([nested]), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
+    with pytest.raises(rt.RtError):
+        s.flatten()
 
 
 def read_glb_positions(path):

@@ -263,3 +263,85 @@ def test_cancellation_false_positive():
     assert radius == pytest.approx(0.2)
     p = ray[0:3, 0].astype(np.float64) + float(t[0]) * ray[3:6, 0].astype(np.float64)
     assert np.linalg.norm(p - centre) > 3 * radius          # the "hit point" is nowhere near the sphere
+
+
+# ---- quadrics and the general Transform.  Every expectation below is worked out by hand
+# from cylinder.rs / cone.rs / paraboloid.rs / hyperboloid.rs / transform.rs; the roots are exact in f32.
+
+def one_hit(scene, o, d, t_min=0.001, t_max=INF):
+    pid, t, n, ff, uv = O.OracleScene(scene).first_hit(ray(o, d), t_min, t_max)
+    return int(pid[0]), float(t[0]), n[0].astype(np.float64), bool(ff[0]), uv[0].astype(np.float64)
+
+
+def test_cylinder_known_answers():
+    two_pi = float(np.float32(np.pi) * np.float32(2))
+    sc = scene_with(lambda s, m: [s.cylinder(1, -0.5, 0.5, two_pi, m)])
+    # a = 1, b = -6, c = 8: q = 4, roots 2 and 4.  The normal is cross(dpdv, dpdu) (cylinder.rs:121), which
+    # points INWARDS, so a ray from outside sees front_face = false and the face-forwarded normal +x.
+    pid, t, n, ff, uv = one_hit(sc, (3, 0, 0), (-1, 0, 0))
+    assert (pid, t, ff) == (0, 2.0, False) and np.allclose(n, [1, 0, 0]) and np.allclose(uv, [0, 0.5])
+    assert one_hit(sc, (3, 0, 0.6), (-1, 0, 0))[0] == 0xFFFFFFFF            # above zmax at both roots
+    assert one_hit(sc, (0, 0, 3), (0, 0, -1))[0] == 0xFFFFFFFF              # along the axis: a = 0, b = 0 -> no roots
+    # half cylinder (phi_max = pi): the near root has phi = 3 pi / 2 > phi_max, the far one phi = pi / 2
+    half = scene_with(lambda s, m: [s.cylinder(1, -0.5, 0.5, float(np.float32(np.pi)), m)])
+    pid, t, n, ff, uv = one_hit(half, (0, -3, 0), (0, 1, 0))
+    assert (pid, t, ff) == (0, 4.0, True) and np.allclose(n, [0, -1, 0], atol=1e-6) and np.allclose(uv, [0.5, 0.5], atol=1e-6)
+    assert one_hit(half, (0, -3, 0), (0, 1, 0), t_max=3.9)[0] == 0xFFFFFFFF  # cylinder.rs:95
+    # t_min is honoured by the cylinder (:68-72): from inside, the root behind the origin is skipped
+    pid, t, n, ff, uv = one_hit(sc, (0, 0, 0), (1, 0, 0))
+    assert (pid, t, ff) == (0, 1.0, True) and np.allclose(n, [-1, 0, 0])
+
+
+def test_cone_known_answers_and_ignored_t_min():
+    two_pi = float(np.float32(np.pi) * np.float32(2))
+    sc = scene_with(lambda s, m: [s.cone(1, 1, two_pi, m)])
+    # k = 1, a = 1, b = -6, c = 9 - 0.25: delta = 1, q = 3.5, roots 2.5 and 3.5; p = (0, 0.5, 0.5), phi = pi/2
+    # dpdu = (-pi, pi, 0) (sic: p.y twice, cone.rs:109), dpdv = (-0, -1, 1): normal = (1, 1, 1) / sqrt 3
+    pid, t, n, ff, uv = one_hit(sc, (0, 3, 0.5), (0, -1, 0))
+    assert (pid, t, ff) == (0, 2.5, True) and np.allclose(n, np.ones(3) / np.sqrt(3), atol=1e-6) and np.allclose(uv, [0.25, 0.5], atol=1e-6)
+    # Cone::hit never looks at t_min (cone.rs:38, 61-65): the hit at t = 2.5 is returned for t_min = 3 too
+    assert one_hit(sc, (0, 3, 0.5), (0, -1, 0), t_min=3.0)[1] == 2.5
+    # with p.y = 0 the sic dpdu is the null vector and so is the normal (normalize of 0, vec3.rs:690-700)
+    pid, t, n, ff, uv = one_hit(sc, (3, 0, 0.5), (-1, 0, 0))
+    assert (pid, t) == (0, 2.5) and np.all(n == 0) and ff is False
+
+
+def test_paraboloid_and_hyperboloid_known_answers():
+    two_pi = float(np.float32(np.pi) * np.float32(2))
+    # Paraboloid::new(0.5, -0.5, 1, 2 pi) of main.rs:932-938: z = 4 (x^2 + y^2)
+    sc = scene_with(lambda s, m: [s.paraboloid(0.5, -0.5, 1.0, two_pi, m)])
+    # a = 4, b = -24, c = 35.75: delta = 4, q = 13, roots 2.75 and 3.25; p = (0, 0.25, 0.25)
+    pid, t, n, ff, uv = one_hit(sc, (0, 3, 0.25), (0, -1, 0))
+    assert (pid, t, ff) == (0, 2.75, True)
+    assert np.allclose(n, np.array([0, 0.75, -0.375]) / np.hypot(0.75, 0.375), atol=1e-6) and np.allclose(uv, [0.25, 0.5], atol=1e-6)
+    # p1 = (1,0,-1), p2 = (1,0,1): ah = 1, ch = 0, the unit cylinder; the normal of a hyperboloid points outwards
+    hy = scene_with(lambda s, m: [s.hyperboloid((1, 0, -1), (1, 0, 1), two_pi, m)])
+    pid, t, n, ff, uv = one_hit(hy, (3, 0, 0), (-1, 0, 0))
+    assert (pid, t, ff) == (0, 2.0, True) and np.allclose(n, [1, 0, 0]) and np.allclose(uv, [0, 0.5])
+    # sic (hyperboloid.rs:116): a negative phi gets + 2, not + 2 pi, on the first attempt.  At p = (0,-1,0)
+    # phi = -pi/2 + 2 = 0.429 <= phi_max = 1, so the near root is ACCEPTED although its true angle is 3 pi / 2
+    hy1 = scene_with(lambda s, m: [s.hyperboloid((1, 0, -1), (1, 0, 1), 1.0, m)])
+    pid, t, n, ff, uv = one_hit(hy1, (0, -3, 0), (0, 1, 0))
+    assert (pid, t) == (0, 2.0) and np.isclose(uv[0], 2.0 - np.pi / 2, atol=1e-6)
+
+
+def test_transform_known_answers():
+    # Transform(translate(10,0,0) * scale(2), unit cube): object-space ray o = (5, .15, .1), d = (-.5, 0, 0) meets
+    # the YZ side at x = 0.5 for t = 9 (t is kept, transform.rs:198-202); p goes back to world space
+    m2w = np.array([[2, 0, 0, 10], [0, 2, 0, 0], [0, 0, 2, 0], [0, 0, 0, 1]], np.float32)
+    sc = scene_with(lambda s, m: [s.transform(s.block((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), m), m2w)])
+    pid, t, n, ff, uv = one_hit(sc, (20, 0.3, 0.2), (-1, 0, 0))
+    assert (pid, t, ff) == (4, 9.0, True) and np.allclose(n, [1, 0, 0]) and np.allclose(uv, [0.65, 0.6], atol=1e-6)
+    # non-uniform scale: the normal goes through adjoint(world2object)^T and is re-normalised (:171, 196-200).
+    # adjoint(W) = det(W) W^-1, so that matrix is proportional to obj2world^T, NOT to the inverse transpose a
+    # normal needs: reference behaviour, kept.  Sphere scaled by (1, 2, 1) at the point (s, 2s, 0), s = 1/sqrt 2:
+    # the object normal (s, s, 0) becomes (1, 2, 0) / sqrt 5 (the ellipsoid's true normal there is (2, 1, 0) / sqrt 5)
+    el = scene_with(lambda s, m: [s.transform(s.sphere((0, 0, 0), 1, m), np.diag([1.0, 2.0, 1.0, 1.0]))])
+    s_ = 1 / np.sqrt(2)
+    pid, t, n, ff, uv = one_hit(el, (s_ + 2, 2 * s_ + 1, 0), (-2, -1, 0))
+    assert pid == 0 and np.isclose(t, 1.0, atol=1e-6) and np.allclose(n, np.array([1, 2, 0]) / np.sqrt(5), atol=1e-6)
+    # FlipFace inside or outside a Transform flips the flag only
+    for wrap in (lambda s, o: s.flip_face(s.transform(o, m2w)), lambda s, o: s.transform(s.flip_face(o), m2w)):
+        fl = scene_with(lambda s, m: [wrap(s, s.block((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), m))])
+        pid, t, n, ff, uv = one_hit(fl, (20, 0.3, 0.2), (-1, 0, 0))
+        assert (pid, t, ff) == (4, 9.0, False) and np.allclose(n, [1, 0, 0])
