@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 F_BOX = 27          # per child-box test with 1/d hoisted (+3 divides per ray, below)
 F_RAY = 3
 F_SPHERE, F_MOVING_EXTRA, F_RECT, F_TRI = 30, 10, 12, 59
+F_QUADRIC = 21 + 45  # world2object of the ray (2 x 3 rows x 7) + coefficients, roots, one point, atan2, clip (cone.rs:43-100)
 F_ACCEPT = 18       # hit record of the accepted primitive (sphere figure; rect 14, tri 55 are close / rarer)
 F_MEDIUM = 2 * 30 + 12
 F_SHADE = [140, 45, 60, 2, 20]      # lambertian+mixture pdf, metal, dielectric, emitted, isotropic
@@ -34,7 +35,7 @@ PEAK_FP32_VALU_TFLOPS = 157.3       # MI355X_MICROARCH.md "Peak FP32 (vector)"
 def algorithmic_flops(st):
     pt = st["prim_tests"]
     f = st["box_tests"] * F_BOX + st["rays"] * F_RAY
-    f += pt[0] * F_SPHERE + pt[1] * (F_SPHERE + F_MOVING_EXTRA) + (pt[2] + pt[3] + pt[4]) * F_RECT + pt[5] * F_TRI
+    f += pt[0] * F_SPHERE + pt[1] * (F_SPHERE + F_MOVING_EXTRA) + (pt[2] + pt[3] + pt[4]) * F_RECT + pt[5] * F_TRI + sum(pt[6:]) * F_QUADRIC
     f += st["accepted_hits"] * F_ACCEPT + st["medium_tests"] * F_MEDIUM
     f += sum(n * c for n, c in zip(st["shades"], F_SHADE)) + sum(n * c for n, c in zip(st["tex_evals"], F_TEX))
     f += st["light_pdf_evals"] * 30 + st["paths"] * F_CAMERA
