@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--device-bvh", action="store_true", help="build the BVH on the GPU (rt_bvh_build.hip) instead of on the host")
     args = ap.parse_args()
 
     import numpy as np
@@ -80,8 +81,11 @@ def main():
     scene, params, camera, sampler = rt.configs.build(args.workload, **over)
     W, H = params.image_width, params.image_height
     gpu = rt.backend.HipBackend(local_rank)   # raises if the HIP library or the GPU is missing
-    flat = scene.flatten()
+    t_flat = time.perf_counter()
+    flat = scene.flatten(device_bvh=args.device_bvh)
+    t_flat = time.perf_counter() - t_flat
     gpu.upload_scene(flat)
+    info = gpu.scene_info()
     gpu.upload_sampler(sampler)
     spp_begin, spp_count = rank * base_spp, base_spp
 
@@ -150,8 +154,10 @@ def main():
             "config": {"workload": "%s %s %dx%d, %d spp per GPU (%d total), depth %d" % (
                 args.workload, rt.configs.WORKLOADS[args.workload]["scene"], W, H, base_spp, total_spp, params.max_ray_depth),
                 "sharding": "sample ranges per GPU + RCCL reduce to rank 0" if world > 1 else "single GPU",
-                "seed": rt.configs.SEED, "primitives": int(flat.desc.n_prims), "bvh_nodes": int(flat.desc.n_bvh_nodes)},
-            "rays_per_step": total_rays, "paths_per_step": total_paths,
+                "seed": rt.configs.SEED, "primitives": int(flat.desc.n_prims), "bvh_nodes": int(info["n_bvh_nodes"]),
+                       "bvh": "built on the GPU in %.2f ms (host flatten %.2f s)" % (info["bvh_build_ms"], t_flat) if info["built_on_device"]
+                              else "built on the host in %.2f s (flatten)" % t_flat},
+            "rays_per_step": total_rays, "paths_per_step": total_paths, "node_visits_per_ray": round(st["node_visits"] / max(1, st["rays"]), 2),
             "mpaths_per_s": total_paths * args.steps / elapsed / 1e6,
             # lane occupancy per kernel phase (counting variant): lanes working / lanes issued
             "phase_occupancy": {n: (round(l / s_, 4) if s_ else None) for n, l, s_ in zip(

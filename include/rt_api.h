@@ -126,7 +126,21 @@ typedef struct rt_scene_desc {
                                        plane, rectangles.rs:23-34); scanned when a direction component is exactly 0 */
     uint32_t       n_prims;         /* number of primitive ids in the scene */
     const float   *matrices;        uint32_t n_matrices;     /* RT_MATRIX_FLOATS each; slots under one are in the always-list */
+    /* Build the BVH on the GPU instead of taking bvh_nodes (rt_bvh_build.hip): slots
+       [0, always_begin) are given in any order with one conservative box each (lo xyz, hi xyz) and are re-ordered
+       by the build; the always-list must be the tail of the slot array.  bvh_nodes / bvh_root_ref /
+       bvh_stack_depth are ignored.  bvh_leaf_max: 1 or 2 slots per leaf, 0 = the library's choice. */
+    const float   *slot_boxes;      uint32_t build_bvh_on_device;   uint32_t bvh_leaf_max;
 } rt_scene_desc;
+
+/* What rt_scene_upload left on the device (the BVH may have been built there). */
+typedef struct rt_scene_info {
+    uint32_t struct_size;
+    uint32_t n_slots, n_bvh_nodes, bvh_stack_depth;
+    int32_t  bvh_root_ref;
+    uint32_t built_on_device;
+    float    bvh_build_ms;          /* GPU time of the build (HIP events), 0 for a host-built tree */
+} rt_scene_info;
 
 /* Sampler table: SamplerBase<MultiJittered> (raytracer/src/sampling.rs:11-24, 137-163). */
 typedef struct rt_sampler_desc {
@@ -206,6 +220,11 @@ const char *rt_last_error(const rt_ctx *ctx);
 /* Copy the flattened `world` + `lights` to the device.
  * Replaces `Arc::new(world)`, `Arc::new(lights)` handed to the workers, main.rs:1320-1333. */
 int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *scene);
+
+/* Facts about the uploaded scene, and (diagnostics / tests) a copy of its BVH nodes and slots as the kernels read them:
+ * nodes = n_bvh_nodes * RT_NODE_FLOATS floats, slots = n_slots * RT_SLOT_FLOATS floats (either may be NULL). */
+int rt_scene_query(rt_ctx *ctx, rt_scene_info *info);
+int rt_scene_read_bvh(rt_ctx *ctx, float *nodes, float *slots);
 
 /* Copy the sampler table to the device.  Replaces `s.clone()` per worker, main.rs:1324,1335. */
 int rt_sampler_upload(rt_ctx *ctx, const rt_sampler_desc *sampler);

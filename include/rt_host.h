@@ -141,6 +141,10 @@ void rth_sampler_desc(const rth_sampler *s, rt_sampler_desc *out);
 typedef struct rth_flat rth_flat;
 /* Lower the object tree to the arrays of rt_scene_desc and build the traversal BVH. */
 int  rth_flatten(const rtg_graph *g, rth_flat **out);
+/* flags: RTH_FLATTEN_DEVICE_BVH = build no tree here; the desc then carries one box per slot and asks
+ * rt_scene_upload to build the BVH on the GPU (rt_scene_desc.build_bvh_on_device). */
+enum { RTH_FLATTEN_DEVICE_BVH = 1 };
+int  rth_flatten_opts(const rtg_graph *g, uint32_t flags, rth_flat **out);
 void rth_flat_free(rth_flat *f);
 void rth_flat_desc(const rth_flat *f, rt_scene_desc *out);
 

@@ -47,7 +47,13 @@ class rt_scene_desc(C.Structure):
         ("rect_slots", c_u32_p), ("n_rect_slots", C.c_uint32),
         ("n_prims", C.c_uint32),
         ("matrices", c_float_p), ("n_matrices", C.c_uint32),
+        ("slot_boxes", c_float_p), ("build_bvh_on_device", C.c_uint32), ("bvh_leaf_max", C.c_uint32),
     ]
+
+
+class rt_scene_info(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_slots", C.c_uint32), ("n_bvh_nodes", C.c_uint32), ("bvh_stack_depth", C.c_uint32),
+                ("bvh_root_ref", C.c_int32), ("built_on_device", C.c_uint32), ("bvh_build_ms", C.c_float)]
 
 
 class rt_sampler_desc(C.Structure):
@@ -166,12 +172,12 @@ HOST_SYMBOLS = [
     "rth_config_free", "rth_config_active_scene", "rth_config_scene_params", "rth_image_height", "rth_camera_new",
     "rth_sampler_new", "rth_sampler_free", "rth_sampler_desc", "rth_flatten", "rth_flat_free", "rth_flat_desc",
     "rth_work_blocks", "rth_mat4_mul", "rth_mat4_invert", "rth_add_transform", "rth_add_cylinder", "rth_add_cone",
-    "rth_add_paraboloid", "rth_add_hyperboloid",
+    "rth_add_paraboloid", "rth_add_hyperboloid", "rth_flatten_opts",
 ]
 
 HIP_SYMBOLS = [
     "rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_scene_upload", "rt_sampler_upload", "rt_render",
-    "rt_resolve", "rt_trace_first_hit", "rt_synchronize", "rt_device_info",
+    "rt_resolve", "rt_trace_first_hit", "rt_synchronize", "rt_device_info", "rt_scene_query", "rt_scene_read_bvh",
 ]
 
 _host = None
@@ -239,6 +245,7 @@ def host_lib():
     L.rth_sampler_free.argtypes = [vp]
     L.rth_sampler_desc.argtypes = [vp, C.POINTER(rt_sampler_desc)]; L.rth_sampler_desc.restype = None
     L.rth_flatten.argtypes = [C.POINTER(rtg_graph), C.POINTER(vp)]
+    L.rth_flatten_opts.argtypes = [C.POINTER(rtg_graph), u32, C.POINTER(vp)]
     L.rth_flat_free.argtypes = [vp]
     L.rth_flat_desc.argtypes = [vp, C.POINTER(rt_scene_desc)]; L.rth_flat_desc.restype = None
     L.rth_work_blocks.argtypes = [i32, i32, i32, C.POINTER(i32), i32]
@@ -264,6 +271,8 @@ def hip_lib():
     L.rt_destroy.argtypes = [vp]; L.rt_destroy.restype = None
     L.rt_last_error.argtypes = [vp]; L.rt_last_error.restype = C.c_char_p
     L.rt_scene_upload.argtypes = [vp, C.POINTER(rt_scene_desc)]
+    L.rt_scene_query.argtypes = [vp, C.POINTER(rt_scene_info)]
+    L.rt_scene_read_bvh.argtypes = [vp, c_float_p, c_float_p]
     L.rt_sampler_upload.argtypes = [vp, C.POINTER(rt_sampler_desc)]
     L.rt_render.argtypes = [vp, C.POINTER(rt_render_params), C.c_void_p, C.POINTER(rt_stats)]
     L.rt_resolve.argtypes = [vp, C.c_void_p, i32, i32, C.c_void_p, i32, vp]

@@ -38,6 +38,21 @@ class HipBackend:
         self._check(self._L.rt_scene_upload(self._h, C.byref(flat.desc)))
         self._flat = flat
 
+    def scene_info(self):
+        """rt_scene_query as a dict (n_slots, n_bvh_nodes, bvh_stack_depth, bvh_root_ref, built_on_device, bvh_build_ms)."""
+        info = _ffi.rt_scene_info()
+        info.struct_size = C.sizeof(info)
+        self._check(self._L.rt_scene_query(self._h, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in _ffi.rt_scene_info._fields_ if k != "struct_size"}
+
+    def read_bvh(self):
+        """(nodes, slots) as the kernels read them (diagnostics / tests)."""
+        info = self.scene_info()
+        nodes = np.zeros((info["n_bvh_nodes"], 16), np.float32)
+        slots = np.zeros((info["n_slots"], 16), np.float32)
+        self._check(self._L.rt_scene_read_bvh(self._h, nodes.ctypes.data_as(_ffi.c_float_p), slots.ctypes.data_as(_ffi.c_float_p)))
+        return nodes, slots
+
     def upload_sampler(self, sampler):
         self._check(self._L.rt_sampler_upload(self._h, C.byref(sampler.desc)))
         self._sampler = sampler

@@ -1,0 +1,310 @@
+// rt_bvh_build.hip — the traversal BVH built on the GPU (load time of multi-million-triangle scenes).
+//
+// The reference has nothing like it: its BvhNode::new (raytracer/src/bvh.rs:15-55) sorts on the CPU, and its
+// TriangleMesh has no tree at all (triangle_mesh.rs:250-267).  The host flattener's binned-SAH build
+// (rt_host_flatten.cpp) takes seconds for the 2.26 M triangles of BASELINE config 4; this one takes milliseconds:
+//
+//   1. 63-bit Morton code of every leaf box centre                      one thread per primitive
+//   2. radix sort of (code, primitive)                                   hipCUB (a plain library sort)
+//   3. binary radix tree over the sorted codes (Karras 2012)             one thread per inner node, no atomics
+//   4. boxes bottom-up: the second child to arrive computes its parent   one thread per leaf, one atomic per node
+//   5. depth of every inner node, then collapse to the 4-wide, 8-bit-quantised nodes of include/rt_api.h:
+//      an inner node at even depth adopts its grandchildren              one thread per inner node + a prefix sum
+//
+// Which tree the kernels walk changes no result: the closest hit and its tie-break do not depend on the order of
+// the search (rt_kernels.h node4_visit), which is what the parity test of this path checks — images bit-identical to
+// the host-built tree's.  All accesses are HBM streams over arrays of n elements; the build is bandwidth- and
+// latency-bound integer work, no LDS tiling needed.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cfloat>
+#include <cstdint>
+#include <string>
+
+#include "rt_api.h"
+#include "rt_bvh_build.h"
+
+namespace rtb {
+namespace {
+
+#define RTB_TRY(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) { *err = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP; } \
+    } while (0)
+
+__device__ __forceinline__ unsigned long long spread3(unsigned long long x) {   // 21 bits -> every third bit
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+struct Bounds { float lo[3], inv[3]; };   // centroid -> [0, 1): (c - lo) * inv
+
+__global__ void __launch_bounds__(256) morton_kernel(const float *__restrict__ boxes, uint32_t n, Bounds b, unsigned long long *keys, uint32_t *vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *bx = boxes + 6 * (size_t)i;
+    unsigned long long code = 0;
+    for (int a = 0; a < 3; ++a) {
+        float c = 0.5f * (bx[a] + bx[3 + a]);
+        float u = (c - b.lo[a]) * b.inv[a];
+        u = !(u > 0.0f) ? 0.0f : (u > 0.99999994f ? 0.99999994f : u);   // a NaN centre goes to cell 0
+        const unsigned long long q = (unsigned long long)(u * 2097152.0f);
+        code |= spread3(q) << (2 - a);
+    }
+    keys[i] = code;
+    vals[i] = i;
+}
+
+// Length of the common prefix of the sorted keys i and j, ties broken by the position (Karras 2012, sec. 4).
+__device__ __forceinline__ int delta(const unsigned long long *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((unsigned)i ^ (unsigned)j);
+    return __clzll((long long)(a ^ b));
+}
+
+// Child encoding in the binary tree: >= 0 inner node, < 0 leaf ~c (a position in sorted order).
+__global__ void __launch_bounds__(256) radix_tree_kernel(const unsigned long long *__restrict__ keys, int n, int2 *child, int *parent_inner,
+                                                         int *parent_leaf) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n - 1) return;
+    const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int delta_min = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > delta_min) lmax *= 2;   // ends: delta is -1 outside [0, n)
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, n, i, i + (l + t) * d) > delta_min) l += t;
+    const int j = i + l * d;
+    const int delta_node = delta(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, n, i, i + (s + t) * d) > delta_node) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int first = i < j ? i : j, last = i < j ? j : i;
+    int2 c;
+    c.x = first == gamma ? ~gamma : gamma;
+    c.y = last == gamma + 1 ? ~(gamma + 1) : gamma + 1;
+    child[i] = c;
+    if (c.x >= 0) parent_inner[c.x] = i; else parent_leaf[~c.x] = i;
+    if (c.y >= 0) parent_inner[c.y] = i; else parent_leaf[~c.y] = i;
+    if (i == 0) parent_inner[0] = -1;
+}
+
+struct Box6 { float v[6]; };
+__device__ __forceinline__ Box6 load_box(const float *p) { Box6 b; for (int k = 0; k < 6; ++k) b.v[k] = p[k]; return b; }
+__device__ __forceinline__ Box6 child_box(int c, const float *boxes, const uint32_t *perm, const float *ibox) {
+    return c >= 0 ? load_box(ibox + 6 * (size_t)c) : load_box(boxes + 6 * (size_t)perm[~c]);
+}
+
+__global__ void __launch_bounds__(256) fit_kernel(const float *__restrict__ boxes, const uint32_t *__restrict__ perm, int n, const int2 *child,
+                                                  const int *parent_inner, const int *parent_leaf, float *ibox, uint32_t *arrived) {
+    const int leaf = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (leaf >= n) return;
+    int node = parent_leaf[leaf];
+    while (node >= 0) {
+        __threadfence();                                   // my writes below this node are visible before I announce myself
+        if (atomicAdd(&arrived[node], 1u) == 0u) return;   // the sibling's subtree is not done: it will do the parent
+        __threadfence();
+        const int2 c = child[node];
+        const Box6 a = child_box(c.x, boxes, perm, ibox), b = child_box(c.y, boxes, perm, ibox);
+        float *o = ibox + 6 * (size_t)node;
+        for (int k = 0; k < 3; ++k) { o[k] = fminf(a.v[k], b.v[k]); o[3 + k] = fmaxf(a.v[3 + k], b.v[3 + k]); }
+        node = parent_inner[node];
+    }
+}
+
+// An inner node whose two children are leaves becomes ONE leaf of two slots when leaf_max >= 2.
+__device__ __forceinline__ bool is_pair(int2 c, uint32_t leaf_max) { return leaf_max >= 2u && c.x < 0 && c.y < 0; }
+
+__global__ void __launch_bounds__(256) depth_kernel(int n_inner, const int2 *child, const int *parent_inner, uint32_t leaf_max, uint32_t *is_node4,
+                                                    uint32_t *max_depth) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_inner) return;
+    uint32_t depth = 0;
+    for (int p = parent_inner[i]; p >= 0; p = parent_inner[p]) ++depth;
+    const bool node4 = (depth & 1u) == 0u && !is_pair(child[i], leaf_max);
+    is_node4[i] = node4 ? 1u : 0u;
+    if (node4) atomicMax(max_depth, depth);
+}
+
+struct Entry { Box6 box; int32_t ref; };
+
+// ref of a child of a 4-wide node: inner node at even depth -> its 4-wide index; a leaf or a pair -> leaf ref
+__device__ __forceinline__ int32_t entry_ref(int c, const int2 *child, const uint32_t *index4, uint32_t leaf_max) {
+    if (c < 0) return ~(int32_t)(((uint32_t)~c << 3) | 0u);
+    const int2 cc = child[c];
+    if (is_pair(cc, leaf_max)) return ~(int32_t)(((uint32_t)~cc.x << 3) | 1u);   // positions ~cc.x and ~cc.x + 1
+    return (int32_t)index4[c];
+}
+
+__global__ void __launch_bounds__(256) emit_kernel(int n_inner, const int2 *child, const float *boxes, const uint32_t *perm, const float *ibox,
+                                                   const uint32_t *is_node4, const uint32_t *index4, uint32_t leaf_max, float *nodes) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_inner || !is_node4[i]) return;
+    Entry e[4];
+    int n = 0;
+    const int2 c = child[i];
+    const int cs[2] = {c.x, c.y};
+    for (int k = 0; k < 2; ++k) {
+        const int ck = cs[k];
+        if (ck >= 0 && !is_pair(child[ck], leaf_max)) {   // an inner node at odd depth: adopt its children
+            const int2 g = child[ck];
+            e[n].box = child_box(g.x, boxes, perm, ibox); e[n].ref = entry_ref(g.x, child, index4, leaf_max); ++n;
+            e[n].box = child_box(g.y, boxes, perm, ibox); e[n].ref = entry_ref(g.y, child, index4, leaf_max); ++n;
+        } else {
+            e[n].box = child_box(ck, boxes, perm, ibox); e[n].ref = entry_ref(ck, child, index4, leaf_max); ++n;
+        }
+    }
+    // quantise exactly as the host builder does (rt_host_flatten.cpp): planes on the 8-bit grid of the union box,
+    // rounded outwards and checked in double
+    uint32_t q[6] = {0, 0, 0, 0, 0, 0};
+    float origin[3], scale[3];
+    for (int a = 0; a < 3; ++a) {
+        float lo = FLT_MAX, hi = -FLT_MAX;
+        for (int k = 0; k < n; ++k) { lo = fminf(lo, e[k].box.v[a]); hi = fmaxf(hi, e[k].box.v[3 + a]); }
+        origin[a] = lo;
+        scale[a] = (hi - lo) / 255.0f;
+        for (int guard = 0; guard < 64 && (double)origin[a] + (double)scale[a] * 255.0 < (double)hi; ++guard) scale[a] = nextafterf(scale[a], FLT_MAX);
+        for (int k = 0; k < n; ++k) {
+            int ql = 0, qh = 0;
+            if (scale[a] > 0.0f) {
+                ql = (int)floor(((double)e[k].box.v[a] - (double)origin[a]) / (double)scale[a]);
+                qh = (int)ceil(((double)e[k].box.v[3 + a] - (double)origin[a]) / (double)scale[a]);
+                ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+                qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+                while (ql > 0 && (double)origin[a] + (double)scale[a] * ql > (double)e[k].box.v[a]) --ql;
+                while (qh < 255 && (double)origin[a] + (double)scale[a] * qh < (double)e[k].box.v[3 + a]) ++qh;
+            }
+            q[2 * a] |= (uint32_t)ql << (8 * k);
+            q[2 * a + 1] |= (uint32_t)qh << (8 * k);
+        }
+    }
+    float *d = nodes + (size_t)index4[i] * RT_NODE_FLOATS;
+    for (int a = 0; a < 3; ++a) { d[a] = origin[a]; d[3 + a] = scale[a]; }
+    for (int k = 0; k < 6; ++k) d[6 + k] = __uint_as_float(q[k]);
+    for (int k = 0; k < 4; ++k) d[12 + k] = __int_as_float(k < n ? e[k].ref : RT_BVH_EMPTY);
+}
+
+}  // namespace
+
+int build_lbvh(hipStream_t stream, const float *d_boxes, uint32_t n, uint32_t leaf_max, const float lo[3], const float hi[3], Result *out,
+               std::string *err) {
+    *out = Result{};
+    if (n == 0) { out->root_ref = RT_BVH_EMPTY; out->stack_depth = 1; return RT_OK; }
+    if (n >= (1u << 28)) { *err = "too many primitives for the device BVH build"; return RT_E_INVALID; }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    RTB_TRY(hipEventCreate(&ev0));
+    RTB_TRY(hipEventCreate(&ev1));
+    RTB_TRY(hipEventRecord(ev0, stream));
+    const int ni = (int)n - 1;
+    const unsigned gn = (n + 255u) / 256u, gi = ((unsigned)(ni > 0 ? ni : 1) + 255u) / 256u;
+    // one scratch allocation: keys x2, vals x2, child, parents, ibox, arrived, is_node4, index4, max_depth
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_k0 = take(8ull * n), o_k1 = take(8ull * n), o_v0 = take(4ull * n), o_v1 = take(4ull * n), o_child = take(8ull * n),
+                 o_pi = take(4ull * n), o_pl = take(4ull * n), o_ibox = take(24ull * n), o_arr = take(4ull * n), o_is4 = take(4ull * n),
+                 o_ix4 = take(4ull * (n + 1)), o_md = take(256);
+    size_t sort_bytes = 0, scan_bytes = 0;
+    RTB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr,
+                                               (uint32_t *)nullptr, (int)n, 0, 63, stream));
+    RTB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, ni > 0 ? ni + 1 : 1, stream));
+    const size_t o_tmp = take(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
+    char *scratch = nullptr;
+    RTB_TRY(hipMalloc((void **)&scratch, off));
+    auto done = [&](int rc) { (void)hipFree(scratch); (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return rc; };
+#define RTB_TRY2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *err = std::string(#call) + ": " + hipGetErrorString(e_); return done(e_ == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP); } } while (0)
+    auto *k0 = (unsigned long long *)(scratch + o_k0), *k1 = (unsigned long long *)(scratch + o_k1);
+    auto *v0 = (uint32_t *)(scratch + o_v0), *v1 = (uint32_t *)(scratch + o_v1);
+    auto *child = (int2 *)(scratch + o_child);
+    auto *parent_inner = (int *)(scratch + o_pi), *parent_leaf = (int *)(scratch + o_pl);
+    auto *ibox = (float *)(scratch + o_ibox);
+    auto *arrived = (uint32_t *)(scratch + o_arr), *is4 = (uint32_t *)(scratch + o_is4), *ix4 = (uint32_t *)(scratch + o_ix4);
+    auto *max_depth = (uint32_t *)(scratch + o_md);
+
+    Bounds b;
+    for (int a = 0; a < 3; ++a) {
+        b.lo[a] = lo[a];
+        const float ext = hi[a] - lo[a];
+        b.inv[a] = ext > 0.0f ? 1.0f / ext : 0.0f;
+    }
+    hipLaunchKernelGGL(morton_kernel, dim3(gn), dim3(256), 0, stream, d_boxes, n, b, k0, v0);
+    RTB_TRY2(hipcub::DeviceRadixSort::SortPairs(scratch + o_tmp, sort_bytes, k0, k1, v0, v1, (int)n, 0, 63, stream));
+    uint32_t *perm = nullptr;
+    RTB_TRY2(hipMalloc((void **)&perm, 4ull * n));
+    out->perm = perm;
+    RTB_TRY2(hipMemcpyAsync(perm, v1, 4ull * n, hipMemcpyDeviceToDevice, stream));
+    if (n == 1 || (n == 2 && leaf_max >= 2u)) {   // the whole scene is one leaf
+        out->root_ref = ~(int32_t)((0u << 3) | (n - 1u));
+        out->stack_depth = 1;
+    } else {
+        RTB_TRY2(hipMemsetAsync(arrived, 0, 4ull * n, stream));
+        RTB_TRY2(hipMemsetAsync(max_depth, 0, 4, stream));
+        hipLaunchKernelGGL(radix_tree_kernel, dim3(gi), dim3(256), 0, stream, k1, (int)n, child, parent_inner, parent_leaf);
+        hipLaunchKernelGGL(fit_kernel, dim3(gn), dim3(256), 0, stream, d_boxes, perm, (int)n, child, parent_inner, parent_leaf, ibox, arrived);
+        hipLaunchKernelGGL(depth_kernel, dim3(gi), dim3(256), 0, stream, ni, child, parent_inner, leaf_max, is4, max_depth);
+        RTB_TRY2(hipMemsetAsync(is4 + ni, 0, 4, stream));   // the scan runs over ni + 1 flags: its last output is the node count
+        RTB_TRY2(hipcub::DeviceScan::ExclusiveSum(scratch + o_tmp, scan_bytes, is4, ix4, ni + 1, stream));
+        uint32_t h[2] = {0, 0};
+        RTB_TRY2(hipMemcpyAsync(&h[0], ix4 + ni, 4, hipMemcpyDeviceToHost, stream));
+        RTB_TRY2(hipMemcpyAsync(&h[1], max_depth, 4, hipMemcpyDeviceToHost, stream));
+        RTB_TRY2(hipStreamSynchronize(stream));
+        const uint32_t n4 = h[0];
+        if (n4 == 0 || n4 > (uint32_t)ni) { *err = "device BVH build: inconsistent node count"; return done(RT_E_HIP); }
+        float *nodes = nullptr;
+        RTB_TRY2(hipMalloc((void **)&nodes, (size_t)n4 * RT_NODE_FLOATS * 4));
+        out->nodes = nodes;
+        out->n_nodes = n4;
+        hipLaunchKernelGGL(emit_kernel, dim3(gi), dim3(256), 0, stream, ni, child, d_boxes, perm, ibox, is4, ix4, leaf_max, nodes);
+        out->root_ref = 0;                       // inner node 0 is the root (depth 0) and the first flag of the scan
+        out->stack_depth = 3u * (h[1] / 2u + 1u) + 2u;   // a visit pushes at most three children
+    }
+    RTB_TRY2(hipGetLastError());
+    RTB_TRY2(hipEventRecord(ev1, stream));
+    RTB_TRY2(hipStreamSynchronize(stream));
+    (void)hipEventElapsedTime(&out->build_ms, ev0, ev1);
+    return done(RT_OK);
+}
+
+namespace {
+__global__ void __launch_bounds__(256) gather_kernel(const float4 *__restrict__ src, const uint32_t *__restrict__ perm, uint32_t n, uint32_t quads, float4 *dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per float4
+    if (i >= (size_t)n * quads) return;
+    const uint32_t e = (uint32_t)(i / quads), k = (uint32_t)(i - (size_t)e * quads);
+    dst[i] = src[(size_t)perm[e] * quads + k];
+}
+__global__ void __launch_bounds__(256) invert_kernel(const uint32_t *__restrict__ perm, uint32_t n, uint32_t *inv) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[perm[i]] = i;
+}
+__global__ void __launch_bounds__(256) remap_kernel(uint32_t *list, uint32_t count, const uint32_t *__restrict__ inv, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count && list[i] < n) list[i] = inv[list[i]];   // entries >= n are always-list slots: they do not move
+}
+}  // namespace
+
+void gather_records(hipStream_t stream, const void *src, const uint32_t *perm, uint32_t n, uint32_t floats_per_record, void *dst) {
+    const uint32_t quads = floats_per_record / 4u;
+    const size_t total = (size_t)n * quads;
+    if (total == 0) return;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const float4 *)src, perm, n, quads, (float4 *)dst);
+}
+
+void invert_permutation(hipStream_t stream, const uint32_t *perm, uint32_t n, uint32_t *inv) {
+    if (n) hipLaunchKernelGGL(invert_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, perm, n, inv);
+}
+
+void remap_slot_list(hipStream_t stream, uint32_t *list, uint32_t count, const uint32_t *inv, uint32_t n) {
+    if (count) hipLaunchKernelGGL(remap_kernel, dim3((count + 255u) / 256u), dim3(256), 0, stream, list, count, inv, n);
+}
+
+}  // namespace rtb

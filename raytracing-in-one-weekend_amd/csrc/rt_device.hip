@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "rt_bvh_build.h"
 #include "rt_kernels.h"
 #include "rt_wavefront.h"
 
@@ -27,6 +28,8 @@ struct rt_ctx {
     DScene sc{};
     bool have_scene = false, have_sampler = false;
     uint32_t stack_depth = 1;
+    uint32_t n_bvh_nodes = 0, built_on_device = 0;
+    float bvh_build_ms = 0.0f;
     unsigned long long *d_stats = nullptr;  // 64 counters
     hipDeviceProp_t prop{};
     // wavefront workspace (grown on demand, kept until rt_destroy)
@@ -75,7 +78,7 @@ int upload(rt_ctx *ctx, std::vector<void *> &owner, const void *src, size_t byte
     HIP_TRY(ctx, hipMalloc(&d, alloc));
     owner.push_back(d);
     HIP_TRY(ctx, hipMemsetAsync(d, 0, alloc < 4096 ? alloc : 64, ctx->stream));
-    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (bytes && src) HIP_TRY(ctx, hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));   // src == null: allocate only
     *dst = static_cast<const T *>(d);
     return RT_OK;
 }
@@ -94,6 +97,7 @@ size_t env_size(const char *name, size_t dflt, size_t lo, size_t hi) {
 }
 
 constexpr int kMaxPipes = 4;
+constexpr uint32_t kMaxStackDepth = 256;   // traversal stack entries; beyond the LDS part they live in HBM
 constexpr size_t kEntryBytes = 72;   // rt_wavefront.h: 4 float4 + 1 float2 per pool entry
 
 PathQ pool_buffer(rt_ctx *ctx, int which) {
@@ -350,15 +354,21 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     if (s->n_lights == 0) return fail(ctx, RT_E_INVALID, "`lights` is empty (the reference indexes objects[random_int(0,-1)], hittable_list.rs:71-75)");
     if ((uint64_t)s->always_begin + s->always_count > s->n_slots) return fail(ctx, RT_E_INVALID, "always-list outside the slot array");
     if (s->n_slots >= (1u << 28)) return fail(ctx, RT_E_INVALID, "too many primitives");
-    if (s->bvh_stack_depth == 0 || s->bvh_stack_depth > 64) return fail(ctx, RT_E_INVALID, "bvh_stack_depth %u out of range", s->bvh_stack_depth);
+    const bool device_build = s->build_bvh_on_device != 0;
+    if (device_build) {
+        if (s->always_begin + s->always_count != s->n_slots) return fail(ctx, RT_E_INVALID, "device BVH build: the always-list must be the tail of the slot array");
+        if (s->always_begin && !s->slot_boxes) return fail(ctx, RT_E_INVALID, "device BVH build: slot_boxes missing");
+        if (s->bvh_leaf_max > 2) return fail(ctx, RT_E_INVALID, "bvh_leaf_max %u: 0, 1 or 2", s->bvh_leaf_max);
+    } else if (s->bvh_stack_depth == 0 || s->bvh_stack_depth > kMaxStackDepth)
+        return fail(ctx, RT_E_INVALID, "bvh_stack_depth %u out of range", s->bvh_stack_depth);
     auto ref_ok = [&](int32_t ref) {
         if (ref == RT_BVH_EMPTY) return true;   // a 4-wide node may have fewer than four children
         if (ref >= 0) return (uint32_t)ref < s->n_bvh_nodes;
         uint32_t code = (uint32_t)~ref;
         return (uint64_t)(code >> 3) + (code & 7u) + 1u <= s->n_slots;
     };
-    if (s->bvh_root_ref != RT_BVH_EMPTY && !ref_ok(s->bvh_root_ref)) return fail(ctx, RT_E_INVALID, "bvh_root_ref out of range");
-    for (uint32_t i = 0; i < s->n_bvh_nodes; ++i) {
+    if (!device_build && s->bvh_root_ref != RT_BVH_EMPTY && !ref_ok(s->bvh_root_ref)) return fail(ctx, RT_E_INVALID, "bvh_root_ref out of range");
+    for (uint32_t i = 0; !device_build && i < s->n_bvh_nodes; ++i) {
         int32_t refs[4];
         memcpy(refs, &s->bvh_nodes[(size_t)i * RT_NODE_FLOATS + 12], 16);
         for (int32_t r : refs)
@@ -423,7 +433,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     DScene &d = ctx->sc;
     auto &own = ctx->scene_allocs;
 #define UP(field, src, bytes) if ((st = upload(ctx, own, src, bytes, &d.field)) != RT_OK) return st
-    UP(nodes, s->bvh_nodes, (size_t)s->n_bvh_nodes * RT_NODE_FLOATS * 4);
+    if (!device_build) UP(nodes, s->bvh_nodes, (size_t)s->n_bvh_nodes * RT_NODE_FLOATS * 4);
     {   // device copy of the slots: spheres and rectangles under a transform get that transform's record in
         // words 8..15 (rt_kernels.h SlotRec), so a hit test is one 64-byte fetch
         std::vector<float> dev_slots(s->slots, s->slots + (size_t)s->n_slots * RT_SLOT_FLOATS);
@@ -469,12 +479,91 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     UP(rects, s->rect_slots, (size_t)s->n_rect_slots * 4);
 #undef UP
     d.root_ref = s->bvh_root_ref;
+    ctx->stack_depth = s->bvh_stack_depth;
+    ctx->n_bvh_nodes = s->n_bvh_nodes;
+    ctx->built_on_device = 0;
+    ctx->bvh_build_ms = 0.0f;
+    if (device_build) {
+        // Morton order decides where a slot goes: build over the boxes, then gather slots and triangle attributes into
+        // that order and translate the two slot-index lists.  The always-list (the tail) stays where it is.
+        const uint32_t nb = s->always_begin;
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (uint32_t i = 0; i < nb; ++i)
+            for (int a = 0; a < 3; ++a) {
+                const float c = 0.5f * (s->slot_boxes[6 * (size_t)i + a] + s->slot_boxes[6 * (size_t)i + 3 + a]);
+                if (c < lo[a]) lo[a] = c;
+                if (c > hi[a]) hi[a] = c;
+            }
+        const float *d_boxes = nullptr;
+        std::vector<void *> tmp;
+        auto cleanup = [&](int rc) { (void)hipStreamSynchronize(ctx->stream); free_all(tmp); return rc; };
+        if ((st = upload(ctx, tmp, s->slot_boxes, (size_t)nb * 24, &d_boxes)) != RT_OK) return cleanup(st);
+        rtb::Result res;
+        std::string err;
+        const uint32_t leaf_max = s->bvh_leaf_max ? s->bvh_leaf_max : (nb >= 100000u ? 2u : 1u);   // as the host builder chooses
+        st = rtb::build_lbvh(ctx->stream, d_boxes, nb, leaf_max, lo, hi, &res, &err);
+        if (res.nodes) own.push_back(res.nodes);
+        if (res.perm) tmp.push_back(res.perm);
+        if (st != RT_OK) return cleanup(fail(ctx, st, "device BVH build: %s", err.c_str()));
+        if (res.stack_depth > kMaxStackDepth) return cleanup(fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "device BVH build: tree too deep (stack %u)", res.stack_depth));
+        if (nb) {
+            const float4 *sorted_slots = nullptr, *sorted_attrs = nullptr;
+            const uint32_t *inv = nullptr;
+            if ((st = upload(ctx, own, nullptr, (size_t)s->n_slots * RT_SLOT_FLOATS * 4, &sorted_slots)) != RT_OK) return cleanup(st);
+            rtb::gather_records(ctx->stream, d.slots, res.perm, nb, RT_SLOT_FLOATS, const_cast<float4 *>(sorted_slots));
+#define HIP_TRY_C(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return cleanup(fail(ctx, RT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_))); } while (0)
+            if (s->always_count)
+                HIP_TRY_C(hipMemcpyAsync(const_cast<float4 *>(sorted_slots) + 4 * (size_t)nb, d.slots + 4 * (size_t)nb, (size_t)s->always_count * RT_SLOT_FLOATS * 4,
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+            d.slots = sorted_slots;   // the unsorted copy stays in scene_allocs until the next upload
+            if (tris) {
+                if ((st = upload(ctx, own, nullptr, (size_t)s->n_slots * RT_ATTR_FLOATS * 4, &sorted_attrs)) != RT_OK) return cleanup(st);
+                rtb::gather_records(ctx->stream, d.attrs, res.perm, nb, RT_ATTR_FLOATS, const_cast<float4 *>(sorted_attrs));
+                if (s->always_count)
+                    HIP_TRY_C(hipMemcpyAsync(const_cast<float4 *>(sorted_attrs) + 4 * (size_t)nb, d.attrs + 4 * (size_t)nb, (size_t)s->always_count * RT_ATTR_FLOATS * 4,
+                                             hipMemcpyDeviceToDevice, ctx->stream));
+                d.attrs = sorted_attrs;
+            }
+            if ((st = upload(ctx, tmp, nullptr, (size_t)nb * 4, &inv)) != RT_OK) return cleanup(st);
+            rtb::invert_permutation(ctx->stream, res.perm, nb, const_cast<uint32_t *>(inv));
+            rtb::remap_slot_list(ctx->stream, const_cast<uint32_t *>(d.moving), s->n_moving_slots, inv, nb);
+            rtb::remap_slot_list(ctx->stream, const_cast<uint32_t *>(d.rects), s->n_rect_slots, inv, nb);
+            HIP_TRY_C(hipGetLastError());
+#undef HIP_TRY_C
+        }
+        d.nodes = reinterpret_cast<const float4 *>(res.nodes);
+        d.root_ref = res.root_ref;
+        ctx->stack_depth = res.stack_depth;
+        ctx->n_bvh_nodes = res.n_nodes;
+        ctx->built_on_device = 1;
+        ctx->bvh_build_ms = res.build_ms;
+        if ((st = cleanup(RT_OK)) != RT_OK) return st;
+    }
     d.n_slots = s->n_slots;
     d.always_begin = s->always_begin; d.always_count = s->always_count;
     d.n_media = s->n_media; d.n_lights = s->n_lights; d.n_moving = s->n_moving_slots; d.n_rects = s->n_rect_slots;
-    ctx->stack_depth = s->bvh_stack_depth;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_scene = true;
+    return RT_OK;
+}
+
+int rt_scene_query(rt_ctx *ctx, rt_scene_info *info) {
+    if (!ctx) return RT_E_INVALID;
+    if (!info || info->struct_size != sizeof(rt_scene_info)) return fail(ctx, RT_E_INVALID, "rt_scene_query: bad struct size");
+    if (!ctx->have_scene) return fail(ctx, RT_E_INVALID, "rt_scene_query: upload a scene first");
+    info->n_slots = ctx->sc.n_slots; info->n_bvh_nodes = ctx->n_bvh_nodes; info->bvh_stack_depth = ctx->stack_depth;
+    info->bvh_root_ref = ctx->sc.root_ref; info->built_on_device = ctx->built_on_device; info->bvh_build_ms = ctx->bvh_build_ms;
+    return RT_OK;
+}
+
+int rt_scene_read_bvh(rt_ctx *ctx, float *nodes, float *slots) {
+    if (!ctx) return RT_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RT_E_INVALID, "rt_scene_read_bvh: upload a scene first");
+    int st = set_device(ctx);
+    if (st) return st;
+    if (nodes && ctx->n_bvh_nodes) HIP_TRY(ctx, hipMemcpyAsync(nodes, ctx->sc.nodes, (size_t)ctx->n_bvh_nodes * RT_NODE_FLOATS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (slots && ctx->sc.n_slots) HIP_TRY(ctx, hipMemcpyAsync(slots, ctx->sc.slots, (size_t)ctx->sc.n_slots * RT_SLOT_FLOATS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
 
@@ -628,17 +717,20 @@ int rt_trace_first_hit(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_mi
     if (st) return st;
     size_t N = (size_t)n;
     char *d = nullptr;
-    // one allocation: rays 28N | prim 4N | t 4N | normal 12N | uv 8N | ff N
-    size_t off_prim = 28 * N, off_t = 32 * N, off_n = 36 * N, off_uv = 48 * N, off_ff = 56 * N, total = 57 * N;
+    // traversal stack: up to 48 entries per lane in LDS (48 KB per block), a deeper tree's rest in HBM
+    const uint32_t lds_depth = ctx->stack_depth < 48u ? ctx->stack_depth : 48u;
+    const size_t n_threads = (N + 255) / 256 * 256, ovf_bytes = (size_t)(ctx->stack_depth - lds_depth) * n_threads * sizeof(StackEntry);
+    // one allocation: rays 28N | prim 4N | t 4N | normal 12N | uv 8N | ff N | stack overflow
+    size_t off_prim = 28 * N, off_t = 32 * N, off_n = 36 * N, off_uv = 48 * N, off_ff = 56 * N, off_ovf = (57 * N + 255) / 256 * 256, total = off_ovf + ovf_bytes;
     HIP_TRY(ctx, hipMalloc((void **)&d, total));
     hipStream_t stream = ctx->stream;
     hipError_t e = hipMemcpyAsync(d, rays_soa, 28 * N, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) {
         dim3 grid((unsigned)((N + 255) / 256)), block(256);
-        size_t lds = (size_t)ctx->stack_depth * 256 * sizeof(StackEntry);
+        size_t lds = (size_t)lds_depth * 256 * sizeof(StackEntry);
         hipLaunchKernelGGL(first_hit_kernel, grid, block, lds, stream, ctx->sc, (const float *)d, n, t_min, t_max,
                            (uint32_t *)(d + off_prim), (float *)(d + off_t), (float *)(d + off_n), (uint8_t *)(d + off_ff),
-                           (float *)(d + off_uv));
+                           (float *)(d + off_uv), lds_depth, ovf_bytes ? (StackEntry *)(d + off_ovf) : nullptr, (uint32_t)n_threads);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(prim_id, d + off_prim, 4 * N, hipMemcpyDeviceToHost, stream);

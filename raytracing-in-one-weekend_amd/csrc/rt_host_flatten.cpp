@@ -62,6 +62,8 @@ struct rth_flat {
     std::vector<uint32_t> perlin;
     std::vector<uint8_t> texels;
     std::vector<uint32_t> moving, rects;
+    std::vector<float> slot_boxes;   // device-BVH mode: lo xyz, hi xyz per slot
+    bool device_bvh = false;
     int32_t root_ref = RT_BVH_EMPTY;
     uint32_t stack_depth = 1, always_begin = 0, always_count = 0, n_prims = 0;
     bool has_tris = false;
@@ -447,7 +449,9 @@ struct BvhBuilder {
 
 extern "C" {
 
-int rth_flatten(const rtg_graph *g, rth_flat **out_flat) {
+int rth_flatten(const rtg_graph *g, rth_flat **out_flat) { return rth_flatten_opts(g, 0u, out_flat); }
+
+int rth_flatten_opts(const rtg_graph *g, uint32_t flags, rth_flat **out_flat) {
     if (!g || !out_flat) { set_error("null argument"); return RT_E_INVALID; }
     if (g->world_root < 0 || g->lights_root < 0) { set_error("scene roots are not set"); return RT_E_INVALID; }
     auto flat = std::make_unique<rth_flat>();
@@ -518,6 +522,22 @@ int rth_flatten(const rtg_graph *g, rth_flat **out_flat) {
         std::iota(new_index.begin(), new_index.end(), 0u);
         flat->always_begin = 0;
         flat->always_count = (uint32_t)n_all;
+        flat->root_ref = RT_BVH_EMPTY;
+        flat->stack_depth = 1;
+    } else if (flags & RTH_FLATTEN_DEVICE_BVH) {   // no tree here: slots in primitive order, one box each, the always-list behind them
+        flat->slots.resize(n_all);
+        flat->attrs.resize(n_all);
+        flat->slot_boxes.resize(6 * n);
+        for (size_t i = 0; i < n_all; ++i) {
+            const uint32_t prim = i < n ? in_bvh[i] : in_always[i - n];
+            flat->slots[i] = fl.prims[prim];
+            flat->attrs[i] = fl.pattrs[prim];
+            new_index[prim] = (uint32_t)i;
+            if (i < n) { memcpy(&flat->slot_boxes[6 * i], fl.boxes[prim].lo, 12); memcpy(&flat->slot_boxes[6 * i + 3], fl.boxes[prim].hi, 12); }
+        }
+        flat->device_bvh = true;
+        flat->always_begin = (uint32_t)n;
+        flat->always_count = (uint32_t)in_always.size();
         flat->root_ref = RT_BVH_EMPTY;
         flat->stack_depth = 1;
     } else {
@@ -632,6 +652,7 @@ void rth_flat_desc(const rth_flat *f, rt_scene_desc *d) {
     d->tri_attrs = f->attrs.empty() ? nullptr : f->attrs[0].w;
     d->xforms = f->xforms.data();              d->n_xforms = (uint32_t)(f->xforms.size() / RT_REC_FLOATS);
     d->matrices = f->matrices.data();          d->n_matrices = (uint32_t)(f->matrices.size() / RT_MATRIX_FLOATS);
+    d->slot_boxes = f->slot_boxes.data();      d->build_bvh_on_device = f->device_bvh ? 1u : 0u;
     d->media = f->media.data();                d->n_media = (uint32_t)(f->media.size() / RT_REC_FLOATS);
     d->lights = f->lights.data();              d->n_lights = (uint32_t)(f->lights.size() / RT_REC_FLOATS);
     d->materials = f->materials.data();        d->n_materials = (uint32_t)(f->materials.size() / RT_REC_FLOATS);

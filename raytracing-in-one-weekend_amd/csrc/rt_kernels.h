@@ -1295,7 +1295,8 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 
 // Parity hook: world.hit without media for caller-supplied rays (rt_trace_first_hit).
 __global__ void __launch_bounds__(256) first_hit_kernel(DScene sc, const float *__restrict__ rays, int n, float t_min, float t_max,
-                                                        uint32_t *prim_id, float *t_out, float *normal3, uint8_t *front_face, float *uv2) {
+                                                        uint32_t *prim_id, float *t_out, float *normal3, uint8_t *front_face, float *uv2,
+                                                        uint32_t lds_depth, StackEntry *ovf, uint32_t ovf_stride) {
     extern __shared__ StackEntry lds_stack[];
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
@@ -1306,7 +1307,7 @@ __global__ void __launch_bounds__(256) first_hit_kernel(DScene sc, const float *
     Counters cnt{};
     rts::Rng rng{0, 1};
     Hit best;
-    const Stack stack{lds_stack + threadIdx.x, blockDim.x, 0xffffffffu, nullptr, 0u};   // launched with the full BVH depth in LDS
+    const Stack stack{lds_stack + threadIdx.x, blockDim.x, lds_depth, ovf ? ovf + i : nullptr, ovf_stride};   // ovf == null: the whole stack fits LDS
     bool h = closest_hit<false>(sc, r, t_min, t_max, false, rng, best, stack, cnt);
     Rec rec{};
     if (h) rec = slot_record(sc, (uint32_t)best.slot, r, best.t, true, t_min, t_max);

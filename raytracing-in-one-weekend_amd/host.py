@@ -181,10 +181,10 @@ class Assets:
 class FlatScene:
     """Result of the flatten step: host arrays in the layout of include/rt_api.h."""
 
-    def __init__(self, graph_ptr, owner):
+    def __init__(self, graph_ptr, owner, device_bvh=False):
         self._owner = owner
         self._h = C.c_void_p()
-        _check(_ffi.host_lib().rth_flatten(graph_ptr, C.byref(self._h)))
+        _check(_ffi.host_lib().rth_flatten_opts(graph_ptr, 1 if device_bvh else 0, C.byref(self._h)))
         self.desc = _ffi.rt_scene_desc()
         _ffi.host_lib().rth_flat_desc(self._h, C.byref(self.desc))
 
@@ -280,8 +280,9 @@ class Scene:
     def graph(self):
         return _ffi.host_lib().rth_scene_graph(self._h)
 
-    def flatten(self):
-        return FlatScene(self.graph(), self)
+    def flatten(self, device_bvh=False):
+        """device_bvh: leave the BVH to rt_scene_upload, which then builds it on the GPU (rt_bvh_build.hip)."""
+        return FlatScene(self.graph(), self, device_bvh)
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -26,7 +26,7 @@ def test_hip_library_exports_rt_api_h(rt):
     assert os.path.exists(path), "HIP extension not built: run __graft_entry__.build()"
     L = ctypes.CDLL(path)   # links libamdhip64; needs no GPU
     names = declared("rt_api.h", "rt_")
-    assert len(names) == 11
+    assert len(names) == 13
     for n in names:
         assert hasattr(L, n), n
     assert sorted(rt._ffi.HIP_SYMBOLS) == names
@@ -36,15 +36,15 @@ def test_struct_sizes_match_the_headers(rt, tmp_path):
     """ctypes mirrors vs sizeof() as the C compiler sees the headers."""
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "rt_host.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "rt_host.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(rt_scene_desc),sizeof(rt_sampler_desc),sizeof(rt_camera),sizeof(rt_render_params),sizeof(rt_stats),'
-                   'sizeof(rtg_node),sizeof(rtg_graph),sizeof(rth_user_config),sizeof(rth_scene_assets));return 0;}\n')
+                   'sizeof(rtg_node),sizeof(rtg_graph),sizeof(rth_user_config),sizeof(rth_scene_assets),sizeof(rt_scene_info));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     f = rt._ffi
     want = [ctypes.sizeof(t) for t in (f.rt_scene_desc, f.rt_sampler_desc, f.rt_camera, f.rt_render_params, f.rt_stats,
-                                       f.rtg_node, f.rtg_graph, f.rth_user_config, f.rth_scene_assets)]
+                                       f.rtg_node, f.rtg_graph, f.rth_user_config, f.rth_scene_assets, f.rt_scene_info)]
     assert got == want
 
 
