@@ -8,6 +8,8 @@
  *   scene_random_world / scene_cornell_box /
  *   scene_final_chapter2 / scene_mesh                      raytracer/src/main.rs:106-199, 362-522, 685-828, 969-1029
  *   scene_geometric_primitives / scene_blocks              raytracer/src/main.rs:830-967, 1031-1133
+ *   scene_two_spheres / _two_perlin_spheres /
+ *   _textured_spheres / _simple_light                      raytracer/src/main.rs:201-360
  *   ImportedGeometry (GLB) + TriangleMesh::new             raytracer/src/geometry_import.rs:306-507, triangle_mesh.rs:43-119
  *   "Hittable::flatten" (does not exist in the reference)  object tree -> flat arrays + BVH of include/rt_api.h
  *
@@ -99,7 +101,7 @@ typedef struct rth_scene_assets {
 } rth_scene_assets;
 
 /* name = a `Scene` variant of main.rs:93-104: "RandomWorld", "CornellBox", "Chapter2Final",
- * "MeshTest", "GeometricPrimitives", "Blocks".  seed feeds every random_* call of the builder (the reference is unseeded). */
+ * "MeshTest", "GeometricPrimitives", "Blocks", "TwoSpheres", "PerlinSpheres", "TexturedSpheres", "SimpleLight" — all ten.  seed feeds every random_* call of the builder (the reference is unseeded). */
 int rth_build_scene(rth_scene *s, const char *name, uint32_t seed, const rth_scene_assets *assets);
 
 /* ------------------------------------------------------------------ config (RON) */

@@ -9,6 +9,7 @@ image size / spp of BASELINE.json on top:
 and the reference's two remaining scenes with their shipped configs:
   GP      GeometricPrimitives  800x600 256 spp  SphericalPanoramic camera; blocks, cylinders, cones, paraboloids
   BLOCKS  Blocks               800x600 256 spp  three checkered blocks under general Transforms
+  TWO / PERLIN / LIGHT / EARTH  TwoSpheres, PerlinSpheres, SimpleLight, TexturedSpheres (main.rs:201-360): a handful of spheres each
 """
 from . import host
 
@@ -21,6 +22,12 @@ WORKLOADS = {
     "C4": dict(scene="MeshTest", image_width=1920, aspect_ratio=1920.0 / 1080.0, samples_per_pixel=256, mesh_grid=10),
     "GP": dict(scene="GeometricPrimitives"),
     "BLOCKS": dict(scene="Blocks"),
+    "TWO": dict(scene="TwoSpheres"),
+    "PERLIN": dict(scene="PerlinSpheres"),
+    "LIGHT": dict(scene="SimpleLight"),
+    # not in the reference's defined_scenes (and not reachable from its scene switch): default_params, camera pulled back
+    "EARTH": dict(scene="TexturedSpheres", config_scene="CornellBox", look_from=(13.0, 2.0, 3.0), look_at=(0.0, 0.0, 0.0),
+                  vertical_fov=20.0, background=(0.7, 0.8, 1.0)),
 }
 
 
@@ -30,8 +37,9 @@ def workload(name, config=None, **overrides):
     w.update(overrides)
     scene = w.pop("scene")
     mesh_grid = w.pop("mesh_grid", 1)
+    config_scene = w.pop("config_scene", scene)
     cfg = config or host.RaytracerConfig.load()
-    params = cfg.scene_params(scene).replace(**w)
+    params = cfg.scene_params(config_scene).replace(**w)
     return scene, params, mesh_grid
 
 
@@ -40,7 +48,8 @@ def build(name, config=None, seed=SEED, **overrides):
     scene_name, params, mesh_grid = workload(name, config, **overrides)
     need = {"RandomWorld": (), "CornellBox": (), "Chapter2Final": ("earthmap",),
             "MeshTest": ("uvgrid01", "uvgrid09", "teapot"), "Blocks": ("uvgrid01",),
-            "GeometricPrimitives": ("uvgrid01", "uvgrid03", "uvgrid08", "uvgrid10")}[scene_name]
+            "GeometricPrimitives": ("uvgrid01", "uvgrid03", "uvgrid08", "uvgrid10"), "TwoSpheres": (), "SimpleLight": (),
+            "PerlinSpheres": ("uvgrid01", "uvgrid03"), "TexturedSpheres": ("earthmap",)}[scene_name]
     assets = host.Assets(mesh_grid=mesh_grid, need=need) if need else None
     scene = host.Scene.build(scene_name, seed, assets)
     sampler = host.MultiJitteredSampler(params.samples_per_pixel, seed=seed)

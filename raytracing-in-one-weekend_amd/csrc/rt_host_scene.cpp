@@ -570,6 +570,63 @@ int build_random_world(Builder &b) {
     return rth_set_roots(s, wl, ll);
 }
 
+// The dummy `lights` list of the small scenes (main.rs:219-228 and its copies): a black XZRect far away
+int finish_with_dummy_light(Builder &b, std::vector<int32_t> &world) {
+    rth_scene *s = b.s;
+    for (int32_t w : world) if (w < 0) return w;
+    int32_t l = rth_add_rect(s, RTG_XZ_RECT, 213.0f, 343.0f, 227.0f, 332.0f, 554.0f, b.light(0, 0, 0));
+    int wl = rth_add_list(s, world.data(), (int)world.size());
+    int ll = rth_add_list(s, &l, 1);
+    return rth_set_roots(s, wl, ll);
+}
+
+// main.rs:201-231
+int build_two_spheres(Builder &b) {
+    rth_scene *s = b.s;
+    int checker = rth_add_lambertian(s, rth_add_checker_texture(s, rth_add_solid_texture(s, 0.2f, 0.3f, 0.1f), rth_add_solid_texture(s, 0.9f, 0.9f, 0.9f), 4.0f));
+    const float lo[3] = {0, -10, 0}, hi[3] = {0, 10, 0};
+    std::vector<int32_t> world = {rth_add_sphere(s, lo, 10, checker), rth_add_sphere(s, hi, 10, checker)};
+    return finish_with_dummy_light(b, world);
+}
+
+// main.rs:233-286
+int build_two_perlin_spheres(Builder &b, const rth_scene_assets *assets, uint32_t seed) {
+    rth_scene *s = b.s;
+    if (!assets) { set_error("PerlinSpheres needs assets->uvgrid01 and uvgrid03"); return RT_E_INVALID; }
+    int noise_mtl = rth_add_lambertian(s, rth_add_noise_texture(s, 3.0f, seed));
+    const rth_image &g1 = assets->uvgrid01, &g3 = assets->uvgrid03;
+    const float c0[3] = {0, -1000, 0}, c1[3] = {4, 4, 0}, c2[3] = {-6, 6, 2};
+    std::vector<int32_t> world;
+    world.push_back(rth_add_sphere(s, c0, 1000, rth_add_lambertian(s, rth_add_image_texture(s, g1.width, g1.height, g1.rgba))));
+    world.push_back(rth_add_sphere(s, c1, 3, rth_add_lambertian(s, rth_add_image_texture(s, g3.width, g3.height, g3.rgba))));
+    world.push_back(rth_add_sphere(s, c2, 6, noise_mtl));
+    world.push_back(rth_add_flip_face(s, rth_add_rect(s, RTG_XZ_RECT, -1000, 1000, -1000, 1000, 1000, b.light(1, 1, 1))));
+    return finish_with_dummy_light(b, world);
+}
+
+// main.rs:288-313 (built by the reference but not reachable from its scene switch, main.rs:1311)
+int build_textured_spheres(Builder &b, const rth_scene_assets *assets) {
+    rth_scene *s = b.s;
+    const rth_image *earth = assets ? &assets->earthmap : nullptr;
+    int etex = rth_add_image_texture(s, earth ? earth->width : 0, earth ? earth->height : 0, earth ? earth->rgba : nullptr);
+    const float c[3] = {0, 0, 0};
+    std::vector<int32_t> world = {rth_add_sphere(s, c, 2, rth_add_lambertian(s, etex))};
+    return finish_with_dummy_light(b, world);
+}
+
+// main.rs:315-360
+int build_simple_light(Builder &b, uint32_t seed) {
+    rth_scene *s = b.s;
+    int noise_mtl = rth_add_lambertian(s, rth_add_noise_texture(s, 3.0f, seed));
+    const float c0[3] = {0, -1000, 0}, c1[3] = {0, 2, 0}, c2[3] = {0, 8, 0};
+    std::vector<int32_t> world;
+    world.push_back(rth_add_sphere(s, c0, 1000, noise_mtl));
+    world.push_back(rth_add_sphere(s, c1, 2, noise_mtl));
+    world.push_back(rth_add_rect(s, RTG_XY_RECT, 3, 5, 1, 3, -2, b.light(4, 4, 4)));
+    world.push_back(rth_add_sphere(s, c2, 2, b.light(4, 2, 0)));
+    return finish_with_dummy_light(b, world);
+}
+
 // main.rs:362-522
 int build_cornell_box(Builder &b) {
     rth_scene *s = b.s;
@@ -821,6 +878,10 @@ int rth_build_scene(rth_scene *s, const char *name, uint32_t seed, const rth_sce
     if (n == "CornellBox") return build_cornell_box(b);
     if (n == "Chapter2Final") return build_final_chapter2(b, assets, seed);
     if (n == "MeshTest") return build_mesh_test(b, assets);
+    if (n == "TwoSpheres") return build_two_spheres(b);
+    if (n == "PerlinSpheres") return build_two_perlin_spheres(b, assets, seed);
+    if (n == "TexturedSpheres") return build_textured_spheres(b, assets);
+    if (n == "SimpleLight") return build_simple_light(b, seed);
     if (n == "GeometricPrimitives") return build_geometric_primitives(b, assets);
     if (n == "Blocks") return build_blocks(b, assets);
     set_error("scene '%s' is not covered by this backend", name);

@@ -203,7 +203,8 @@ class FlatScene:
 class Scene:
     """A `(world, lights)` pair as returned by the reference's scene_*() functions."""
 
-    SUPPORTED = ("RandomWorld", "CornellBox", "Chapter2Final", "MeshTest", "GeometricPrimitives", "Blocks")
+    SUPPORTED = ("RandomWorld", "TwoSpheres", "TexturedSpheres", "PerlinSpheres", "SimpleLight", "CornellBox", "Chapter2Final",
+                 "MeshTest", "GeometricPrimitives", "Blocks")          # every `Scene` variant of main.rs:91-103
 
     def __init__(self):
         self._h = C.c_void_p(_ffi.host_lib().rth_scene_new())

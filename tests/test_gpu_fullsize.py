@@ -127,3 +127,23 @@ def test_c4_mesh_2m_triangles(rt, gpu):
     assert st["paths"] == 1920 * 1080 * 4 and st["prim_tests"][5] > 0
     tile, _ = gpu.render(params, camera, spp_begin=0, spp_count=4, tile=(900, 500, 1000, 580))
     assert np.array_equal(tile[500:580, 900:1000].view(np.uint32), a[500:580, 900:1000].view(np.uint32))
+
+
+@pytest.mark.parametrize("name,windows", [
+    # GeometricPrimitives as shipped (raytracer.config.ron:88-107): 800x600, 256 spp, SphericalPanoramic over 360 x 180 degrees
+    ("GP", (((250, 300, 282, 332), 0), ((520, 260, 552, 292), 128), ((384, 380, 416, 412), 192))),
+    # Blocks as shipped (:130-149): 800x600, 256 spp, aperture 0.5
+    ("BLOCKS", (((300, 200, 332, 232), 0), ((470, 330, 502, 362), 200))),
+])
+def test_quadric_scenes_at_their_shipped_configs(rt, gpu, name, windows):
+    scene, params, camera, sampler = setup(rt, gpu, name)
+    assert (params.image_width, params.image_height, sampler.spp) == (800, 600, 256)
+    oracle = O.OracleScene(scene)
+    for tile, s0 in windows:                                      # 32x32 windows, 48 of the 256 samples each
+        oracle_window(rt, gpu, scene, params, camera, sampler, tile, spp_begin=s0, spp_count=48, oracle=oracle)
+    a, st = gpu.render(params, camera, spp_begin=0, spp_count=8, stats=True)
+    assert st["paths"] == 800 * 600 * 8 and st["node_visits"] == 0       # about 20 leaves, all in the always-list
+    if name == "GP":
+        assert all(st["prim_tests"][k] > 0 for k in (6, 7, 8))           # cylinders, cones, paraboloids
+    tile, _ = gpu.render(params, camera, spp_begin=0, spp_count=8, tile=(96, 40, 300, 177))
+    assert np.array_equal(tile[40:177, 96:300].view(np.uint32), a[40:177, 96:300].view(np.uint32))

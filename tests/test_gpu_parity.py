@@ -79,7 +79,8 @@ def compare_images(rt, gpu, oracle, params, camera, sampler, **kw):
 
 
 @pytest.mark.parametrize("name,width,spp,n_rays", [("C1", 240, 9, 1 << 16), ("C2", 96, 16, 1 << 16), ("C3", 96, 16, 1 << 16),
-                                                   ("C4", 64, 4, 1 << 13), ("GP", 96, 16, 1 << 16), ("BLOCKS", 96, 16, 1 << 16)])
+                                                   ("C4", 64, 4, 1 << 13), ("GP", 96, 16, 1 << 16), ("BLOCKS", 96, 16, 1 << 16),
+                                                   ("TWO", 64, 9, 1 << 12), ("PERLIN", 96, 9, 1 << 14), ("LIGHT", 64, 16, 1 << 14), ("EARTH", 64, 4, 1 << 12)])
 def test_image_and_first_hit_small(rt, gpu, name, width, spp, n_rays):
     extra = {"mesh_grid": 1} if name == "C4" else {}
     scene, params, camera, sampler = rt.configs.build(name, image_width=width, samples_per_pixel=spp, **extra)
@@ -91,7 +92,7 @@ def test_image_and_first_hit_small(rt, gpu, name, width, spp, n_rays):
     g, exact = check_first_hit(gpu, oracle, rays)
     assert exact, "t / normal / uv are expected to be bit-identical"
     hit = g[0] != 0xFFFFFFFF
-    assert hit.mean() > 0.5
+    assert hit.mean() > 0.25
     rays2 = bounce_rays(rays, g[1], g[2], hit)
     check_first_hit(gpu, oracle, rays2)
     compare_images(rt, gpu, oracle, params, camera, sampler)

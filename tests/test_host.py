@@ -136,7 +136,13 @@ def test_scene_builders_object_counts(rt):
     assert f.desc.n_slots == f.desc.n_prims - 2 and f.desc.n_media == 2 and f.desc.n_perlin == 1
     assert f.desc.n_texel_bytes == 1024 * 512 * 4
     with pytest.raises(rt.RtError):
-        rt.host.Scene.build("PerlinSpheres")                      # a Scene variant nobody asked for yet
+        rt.host.Scene.build("NoSuchScene")
+    for name, n_world in (("TwoSpheres", 2), ("PerlinSpheres", 4), ("SimpleLight", 4), ("TexturedSpheres", 1)):   # main.rs:201-360
+        scene, params, camera, sampler = rt.configs.build({"TwoSpheres": "TWO", "PerlinSpheres": "PERLIN", "SimpleLight": "LIGHT",
+                                                           "TexturedSpheres": "EARTH"}[name], samples_per_pixel=4)
+        g, _ = graph_counts(scene)
+        assert g.nodes[g.world_root].child_count == n_world and g.nodes[g.lights_root].child_count == 1
+        assert scene.flatten().desc.n_prims == n_world
 
     s = rt.host.Scene.build("Blocks", assets=rt.host.Assets(need=("uvgrid01",)))
     g, types = graph_counts(s)
