@@ -391,7 +391,7 @@ RT_DEV V3 quadric_record(int type, const SlotRec &s, const QuadHit &h, float *u,
 // EXT = false: without the quadrics and the general Transform (see to_object_rec).
 template <bool STATS, bool EXT = true>
 RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, const Ray &r_world, float t_min, float t_max, float *t_out,
-                         int32_t *id_out, Counters &cnt) {
+                         int32_t *id_out, Counters &cnt, const Ray *r_object = nullptr /* the ray already in the slot's frame */) {
     const float4 q0 = s.q0, meta = s.meta;
     int w4 = f2i(meta.x);
     int type = w4 & 15;
@@ -399,7 +399,8 @@ RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, cons
     *id_out = f2i(meta.z);
     if (STATS) cnt.prim_tests[type] += 1;
     Ray r = r_world;
-    if (xf >= 0) r = type_has_inline_xform(type) ? to_object_rec<EXT>(sc, s.q2, s.q3, r_world) : to_object<EXT>(sc, xf, r_world);
+    if (r_object) r = *r_object;
+    else if (xf >= 0) r = type_has_inline_xform(type) ? to_object_rec<EXT>(sc, s.q2, s.q3, r_world) : to_object<EXT>(sc, xf, r_world);
     if (EXT && type >= RT_PRIM_CYLINDER) {
         QuadHit qh;
         if (!quadric_test(type, s, r, t_min, t_max, &qh)) return false;
@@ -802,12 +803,19 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
     RG_BEGIN(RG_B_ALWAYS);
     if (sc.always_count) {   // the slot index is wave-uniform: fetch slot i+1 while slot i is tested
         SlotRec nx = load_slot(sc, sc.always_begin);
+        int frame_xf = -1;   // consecutive slots under one transform (the six sides of a block) share the transformed ray
+        Ray r_frame = r;
         for (uint32_t i = 0; i < sc.always_count; ++i) {
             const SlotRec cu = nx;
             const uint32_t s = sc.always_begin + i;
             if (i + 1 < sc.always_count) nx = load_slot(sc, s + 1);
+            const int w4 = f2i(cu.meta.x), xf = (w4 >> 8) - 1;   // wave-uniform
+            if (xf != frame_xf) {
+                frame_xf = xf;
+                r_frame = xf < 0 ? r : (type_has_inline_xform(w4 & 15) ? to_object_rec(sc, cu.q2, cu.q3, r) : to_object(sc, xf, r));
+            }
             float t; int32_t id;
-            if (slot_hit_rec<STATS>(sc, s, cu, r, t_min, t_max, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)s);
+            if (slot_hit_rec<STATS>(sc, s, cu, r, t_min, t_max, &t, &id, cnt, &r_frame) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)s);
         }
     }
     RG_END(RG_B_ALWAYS);

@@ -6,12 +6,21 @@ rt = rtiow_loader.load()
 wl, spp = sys.argv[1], int(sys.argv[2])
 scene, params, camera, sampler = rt.configs.build(wl, samples_per_pixel=spp)
 gpu = rt.backend.HipBackend(0); gpu.upload_scene(scene.flatten()); gpu.upload_sampler(sampler)
-if "--child" in sys.argv:
-    gpu.render(params, camera); sys.exit(0)
 _, st = gpu.render(params, camera, stats=True)
-# the timers come from the product kernels of a -DRT_REGION_TIMERS=1 build, printed on stderr by the library
-import subprocess, tempfile
-err = subprocess.run([sys.executable, os.path.abspath(__file__), wl, str(spp), "--child"], capture_output=True, text=True).stderr
+# the timers come from the product kernels of a -DRT_REGION_TIMERS=1 build, printed on stderr by the library:
+# render once more with fd 2 pointed at a temporary file (same process, no child)
+import tempfile
+sys.stderr.flush()
+with tempfile.TemporaryFile() as f:
+    saved = os.dup(2)
+    os.dup2(f.fileno(), 2)
+    try:
+        gpu.render(params, camera)
+    finally:
+        os.dup2(saved, 2)
+        os.close(saved)
+    f.seek(0)
+    err = f.read().decode()
 line_ = [l for l in err.splitlines() if l.startswith("[rt-regions]")]
 if not line_: sys.exit("library was not built with -DRT_REGION_TIMERS=1:\n" + err[-2000:])
 st["region_cycles"] = [int(x) for x in line_[-1].split()[1:]]
