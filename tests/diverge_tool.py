@@ -1,8 +1,9 @@
 """Development aid: find where a GPU path and the oracle's part ways.  Renders a scene on both, picks a pixel whose ray
 counts differ, narrows it to one sample, prints the oracle's bounces (orc_set_trace) and asks the GPU's first-hit hook
-about each of those rays.  One process, no children.  Usage (on a GPU box):  python tools/diverge.py"""
+about each of those rays.  One process, no children.  It lives under tests/ because it uses the oracle (test infrastructure).
+Usage (on a GPU box):  python tests/diverge_tool.py"""
 import os, re, sys, tempfile
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import oracle_ffi as O
 import test_gpu_parity as T
