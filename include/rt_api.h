@@ -245,6 +245,12 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params, float *out_rgba_sum, 
 int rt_resolve(rt_ctx *ctx, const float *rgba_sum, int32_t n_pixels, int32_t spp,
                float *out_rgba, int32_t location, void *stream);
 
+/* The screenshot's pixel format (main.rs:1543-1551: `DynamicImage::ImageRgb32F(..).to_rgb8()`): the gamma pass above, then
+ * image 0.24.6's f32 -> u8 conversion, round(clamp(c, 0, 1) * 255) with halves away from zero.  out_rgb = n_pixels * 3 bytes.
+ * (The reference hands to_rgb8 the first W*H*3 floats of its RGBA buffer, so its own file is scrambled — SURVEY N6; this
+ * writes the image that call means.) */
+int rt_resolve_rgb8(rt_ctx *ctx, const float *rgba_sum, int32_t n_pixels, int32_t spp, uint8_t *out_rgb, int32_t location, void *stream);
+
 /* Parity hook: closest hit of `world` for n given rays (HittableList::hit semantics,
  * hittable_list.rs:39-50, without the stochastic ConstantMedium objects).
  * rays_soa = 7 planes of n floats: ox oy oz dx dy dz time (math/src/ray.rs:10-14).

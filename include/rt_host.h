@@ -155,6 +155,16 @@ void rth_flat_desc(const rth_flat *f, rt_scene_desc *out);
 void rth_mat4_mul(const float a[16], const float b[16], float out[16]);
 int  rth_mat4_invert(const float m[16], float out[16]);
 
+/* ------------------------------------------------------------------ output
+ * The screenshot of main.rs:1543-1556 as an 8-bit RGB PNG (rgb = height * width * 3 bytes, row 0 = top; take them from
+ * rt_resolve_rgb8), and resumable accumulation: the sums of rt_render with the number of samples they hold.  A load checks
+ * that the file belongs to the same frame (size, spp, seed) and its checksum. */
+int rth_write_png_rgb8(const char *path, int32_t width, int32_t height, const uint8_t *rgb);
+int rth_checkpoint_save(const char *path, int32_t width, int32_t height, int32_t samples_per_pixel, int32_t spp_done, uint32_t seed,
+                        const float *rgba_sum);
+int rth_checkpoint_load(const char *path, int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed, float *rgba_sum,
+                        int32_t *spp_done);
+
 /* WorkBlock list of main.rs:1265-1282 (no shuffle): writes up to cap entries of x0,x1,y0,y1
  * and returns the number of blocks. */
 int32_t rth_work_blocks(int32_t width, int32_t height, int32_t block_pixels, int32_t *out_xyxy, int32_t cap);

@@ -1621,6 +1621,18 @@ void orc_resolve(const float *sum, int32_t n_pixels, int32_t spp, float *out) { 
     }
 }
 
+// main.rs:1543-1551: ImageRgb32F -> to_rgb8.  image 0.24.6 (Cargo.lock; not under /root/reference) converts a f32 sample with
+// `(float.clamp(0.0, 1.0) * u8::MAX as f32).round()` (traits.rs, FromPrimitive<f32> for u8); f32::round is half away from zero.
+void orc_resolve_rgb8(const float *sum, int32_t n_pixels, int32_t spp, uint8_t *out) {
+    Real gamma_correct = 1.0f / (Real)spp;
+    for (int32_t i = 0; i < n_pixels; ++i)
+        for (int c = 0; c < 3; ++c) {
+            Real x = sum[4 * i + c];
+            Real v = !pm::is_normal_(x) ? 0.0f : f32_clamp(std::sqrt(x * gamma_correct), 0.0f, 1.0f);
+            out[3 * i + c] = (uint8_t)std::round(f32_clamp(v, 0.0f, 1.0f) * 255.0f);
+        }
+}
+
 int orc_texture_value(const orc_scene *s, int32_t tex, float u, float v, const float p[3], float out_rgb[3]) {
     if (!s || tex < 0 || (size_t)tex >= s->textures.size()) return RT_E_INVALID;
     GlobalOptions go(s);

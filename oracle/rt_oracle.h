@@ -52,6 +52,8 @@ typedef struct orc_render_params {
 /* KAT hook: the ray of get_ray_<projection>(u, v) (camera.rs:82-184) with unit-disk lens sample (dx, dy);
  * out6 = origin, direction.  Returns 0 for FishEye's None. */
 int orc_project(const orc_render_params *p, float u, float v, float dx, float dy, float *out6);
+/* The screenshot's pixels (main.rs:1543-1551): gamma pass, then to_rgb8.  out = n_pixels * 3 bytes. */
+void orc_resolve_rgb8(const float *sum, int32_t n_pixels, int32_t spp, uint8_t *out);
 /* Debugging aid: print one line per bounce of every traced path on stderr (also: env ORC_TRACE). */
 void orc_set_trace(int on);
 

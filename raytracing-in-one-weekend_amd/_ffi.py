@@ -172,12 +172,13 @@ HOST_SYMBOLS = [
     "rth_config_free", "rth_config_active_scene", "rth_config_scene_params", "rth_image_height", "rth_camera_new",
     "rth_sampler_new", "rth_sampler_free", "rth_sampler_desc", "rth_flatten", "rth_flat_free", "rth_flat_desc",
     "rth_work_blocks", "rth_mat4_mul", "rth_mat4_invert", "rth_add_transform", "rth_add_cylinder", "rth_add_cone",
-    "rth_add_paraboloid", "rth_add_hyperboloid", "rth_flatten_opts",
+    "rth_add_paraboloid", "rth_add_hyperboloid", "rth_flatten_opts", "rth_write_png_rgb8", "rth_checkpoint_save",
+    "rth_checkpoint_load",
 ]
 
 HIP_SYMBOLS = [
     "rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_scene_upload", "rt_sampler_upload", "rt_render",
-    "rt_resolve", "rt_trace_first_hit", "rt_synchronize", "rt_device_info", "rt_scene_query", "rt_scene_read_bvh",
+    "rt_resolve", "rt_trace_first_hit", "rt_synchronize", "rt_device_info", "rt_scene_query", "rt_scene_read_bvh", "rt_resolve_rgb8",
 ]
 
 _host = None
@@ -248,6 +249,9 @@ def host_lib():
     L.rth_flatten_opts.argtypes = [C.POINTER(rtg_graph), u32, C.POINTER(vp)]
     L.rth_flat_free.argtypes = [vp]
     L.rth_flat_desc.argtypes = [vp, C.POINTER(rt_scene_desc)]; L.rth_flat_desc.restype = None
+    L.rth_write_png_rgb8.argtypes = [C.c_char_p, i32, i32, c_u8_p]
+    L.rth_checkpoint_save.argtypes = [C.c_char_p, i32, i32, i32, i32, u32, c_float_p]
+    L.rth_checkpoint_load.argtypes = [C.c_char_p, i32, i32, i32, u32, c_float_p, C.POINTER(i32)]
     L.rth_work_blocks.argtypes = [i32, i32, i32, C.POINTER(i32), i32]
     L.rth_mat4_mul.argtypes = [C.c_float * 16, C.c_float * 16, C.c_float * 16]; L.rth_mat4_mul.restype = None
     L.rth_mat4_invert.argtypes = [C.c_float * 16, C.c_float * 16]
@@ -276,6 +280,7 @@ def hip_lib():
     L.rt_sampler_upload.argtypes = [vp, C.POINTER(rt_sampler_desc)]
     L.rt_render.argtypes = [vp, C.POINTER(rt_render_params), C.c_void_p, C.POINTER(rt_stats)]
     L.rt_resolve.argtypes = [vp, C.c_void_p, i32, i32, C.c_void_p, i32, vp]
+    L.rt_resolve_rgb8.argtypes = [vp, C.c_void_p, i32, i32, C.c_void_p, i32, vp]
     L.rt_trace_first_hit.argtypes = [vp, c_float_p, i32, C.c_float, C.c_float, c_u32_p, c_float_p, c_float_p, c_u8_p,
                                      c_float_p]
     L.rt_synchronize.argtypes = [vp, vp]

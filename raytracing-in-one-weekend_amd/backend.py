@@ -107,6 +107,13 @@ class HipBackend:
         self._check(self._L.rt_resolve(self._h, s.ctypes.data, s.size // 4, spp, out.ctypes.data, _ffi.RT_MEM_HOST, None))
         return out
 
+    def resolve_rgb8(self, sum_rgba, spp):
+        """The screenshot's pixels (main.rs:1543-1551): H x W x 3 uint8."""
+        s = np.ascontiguousarray(sum_rgba, np.float32)
+        out = np.zeros(s.shape[:-1] + (3,), np.uint8)
+        self._check(self._L.rt_resolve_rgb8(self._h, s.ctypes.data, s.size // 4, spp, out.ctypes.data, _ffi.RT_MEM_HOST, None))
+        return out
+
     def resolve_device(self, sum_ptr, n_pixels, spp, out_ptr, stream_ptr=None):
         self._check(self._L.rt_resolve(self._h, sum_ptr, n_pixels, spp, out_ptr, _ffi.RT_MEM_DEVICE, stream_ptr))
 

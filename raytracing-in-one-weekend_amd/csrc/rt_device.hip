@@ -707,6 +707,36 @@ int rt_resolve(rt_ctx *ctx, const float *rgba_sum, int32_t n_pixels, int32_t spp
     return RT_OK;
 }
 
+int rt_resolve_rgb8(rt_ctx *ctx, const float *rgba_sum, int32_t n_pixels, int32_t spp, uint8_t *out_rgb, int32_t location, void *stream_) {
+    if (!ctx) return RT_E_INVALID;
+    if (!rgba_sum || !out_rgb || n_pixels < 0 || spp <= 0) return fail(ctx, RT_E_INVALID, "rt_resolve_rgb8: bad arguments");
+    if (n_pixels == 0) return RT_OK;
+    int st = set_device(ctx);
+    if (st) return st;
+    const float inv_spp = 1.0f / (float)spp;
+    dim3 grid((unsigned)((n_pixels + 255) / 256)), block(256);
+    if (location == RT_MEM_DEVICE) {
+        hipLaunchKernelGGL(resolve_rgb8_kernel, grid, block, 0, stream_ ? (hipStream_t)stream_ : nullptr, (const float4 *)rgba_sum, n_pixels, inv_spp, out_rgb);
+        HIP_TRY(ctx, hipGetLastError());
+        return RT_OK;
+    }
+    void *d_in = nullptr, *d_o = nullptr;
+    const size_t in_bytes = (size_t)n_pixels * 16, out_bytes = (size_t)n_pixels * 3;
+    HIP_TRY(ctx, hipMalloc(&d_in, in_bytes));
+    hipError_t e = hipMalloc(&d_o, out_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, rgba_sum, in_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(resolve_rgb8_kernel, grid, block, 0, ctx->stream, (const float4 *)d_in, n_pixels, inv_spp, (uint8_t *)d_o);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_rgb, d_o, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in);
+    if (d_o) (void)hipFree(d_o);
+    if (e != hipSuccess) return fail(ctx, RT_E_HIP, "rt_resolve_rgb8: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
 int rt_trace_first_hit(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_min, float t_max, uint32_t *prim_id, float *t,
                        float *normal3, uint8_t *front_face, float *uv2) {
     if (!ctx) return RT_E_INVALID;

@@ -1338,5 +1338,20 @@ __global__ void __launch_bounds__(256) resolve_kernel(const float4 *__restrict__
     out[i] = o;
 }
 
+// main.rs:1363-1388 followed by image 0.24.6 `to_rgb8` (f32 -> u8: round(clamp(c, 0, 1) * 255), halves away from zero)
+RT_DEV uint32_t to_u8(float sum, float inv_spp) {
+    const float c = !pm::is_normal_(sum) ? 0.0f : f32_clamp(sqrtf(sum * inv_spp), 0.0f, 1.0f);
+    const float x = c * 255.0f, tr = truncf(x);   // f32::round, halves away from zero (x >= 0); not floor(x + 0.5): 0.49999997 + 0.5
+    return (uint32_t)(x - tr >= 0.5f ? tr + 1.0f : tr);   // rounds up to 1.  x - tr is exact
+}
+__global__ void __launch_bounds__(256) resolve_rgb8_kernel(const float4 *__restrict__ sum, int n, float inv_spp, uint8_t *__restrict__ out) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const float4 s = sum[i];
+    out[3 * (size_t)i] = (uint8_t)to_u8(s.x, inv_spp);
+    out[3 * (size_t)i + 1] = (uint8_t)to_u8(s.y, inv_spp);
+    out[3 * (size_t)i + 2] = (uint8_t)to_u8(s.z, inv_spp);
+}
+
 }  // namespace rtk
 #endif

@@ -291,6 +291,29 @@ class Scene:
             self._h = None
 
 
+def write_png(path, rgb8):
+    """The screenshot file of main.rs:1543-1556: H x W x 3 uint8 (HipBackend.resolve_rgb8) as a PNG."""
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    assert a.ndim == 3 and a.shape[2] == 3
+    _check(_ffi.host_lib().rth_write_png_rgb8(path.encode(), a.shape[1], a.shape[0], a.ctypes.data_as(_ffi.c_u8_p)))
+
+
+def checkpoint_save(path, sums, samples_per_pixel, spp_done, seed=0x5EED):
+    """Resumable accumulation: the H x W x 4 f32 sums of rt_render and how many samples they hold."""
+    a = np.ascontiguousarray(sums, np.float32)
+    _check(_ffi.host_lib().rth_checkpoint_save(path.encode(), a.shape[1], a.shape[0], samples_per_pixel, spp_done, seed,
+                                               a.ctypes.data_as(_ffi.c_float_p)))
+
+
+def checkpoint_load(path, width, height, samples_per_pixel, seed=0x5EED):
+    """-> (sums, spp_done); raises RtError if the file is damaged or belongs to another frame."""
+    a = np.zeros((height, width, 4), np.float32)
+    done = C.c_int32()
+    _check(_ffi.host_lib().rth_checkpoint_load(path.encode(), width, height, samples_per_pixel, seed, a.ctypes.data_as(_ffi.c_float_p),
+                                               C.byref(done)))
+    return a, done.value
+
+
 def work_blocks(width, height, block_pixels):
     """WorkBlock list of main.rs:1265-1282 as an (n,4) array of x0,x1,y0,y1."""
     L = _ffi.host_lib()

@@ -51,6 +51,7 @@ def lib():
         L.orc_math.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_int32]; L.orc_math.restype = C.c_float
         L.orc_lights_pdf_value.argtypes = [vp, C.c_float * 3, C.c_float * 3]; L.orc_lights_pdf_value.restype = C.c_float
         L.orc_perlin.argtypes = [C.c_void_p, C.c_float * 3, C.c_int32]; L.orc_perlin.restype = C.c_float
+        L.orc_resolve_rgb8.argtypes = [fp, C.c_int32, C.c_int32, u8p]; L.orc_resolve_rgb8.restype = None
         L.orc_set_trace.argtypes = [C.c_int32]; L.orc_set_trace.restype = None
         _lib = L
     return _lib
@@ -116,6 +117,13 @@ class OracleScene:
         if getattr(self, "_h", None):
             lib().orc_scene_destroy(self._h)
             self._h = None
+
+
+def resolve_rgb8(sum_rgba, spp):
+    s = np.ascontiguousarray(sum_rgba, np.float32)
+    out = np.zeros(s.shape[:-1] + (3,), np.uint8)
+    lib().orc_resolve_rgb8(s.ctypes.data_as(ffi.c_float_p), s.size // 4, spp, out.ctypes.data_as(ffi.c_u8_p))
+    return out
 
 
 def resolve(sum_rgba, spp):
