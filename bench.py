@@ -51,7 +51,8 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--device-bvh", action="store_true", help="build the BVH on the GPU (rt_bvh_build.hip) instead of on the host")
+    ap.add_argument("--device-bvh", nargs="?", const="ploc", default=None, choices=["ploc", "lbvh"],
+                    help="build the BVH on the GPU (rt_bvh_build.hip) instead of on the host: clustering (default) or Morton radix tree")
     args = ap.parse_args()
 
     import numpy as np
@@ -82,8 +83,10 @@ def main():
     W, H = params.image_width, params.image_height
     gpu = rt.backend.HipBackend(local_rank)   # raises if the HIP library or the GPU is missing
     t_flat = time.perf_counter()
-    flat = scene.flatten(device_bvh=args.device_bvh)
+    flat = scene.flatten(device_bvh=args.device_bvh is not None)
     t_flat = time.perf_counter() - t_flat
+    if args.device_bvh == "lbvh" and flat.desc.build_bvh_on_device:
+        flat.desc.build_bvh_on_device = 2      # RT_BVH_DEVICE_LBVH
     gpu.upload_scene(flat)
     info = gpu.scene_info()
     gpu.upload_sampler(sampler)
@@ -155,7 +158,7 @@ def main():
                 args.workload, rt.configs.WORKLOADS[args.workload]["scene"], W, H, base_spp, total_spp, params.max_ray_depth),
                 "sharding": "sample ranges per GPU + RCCL reduce to rank 0" if world > 1 else "single GPU",
                 "seed": rt.configs.SEED, "primitives": int(flat.desc.n_prims), "bvh_nodes": int(info["n_bvh_nodes"]),
-                       "bvh": "built on the GPU in %.2f ms (host flatten %.2f s)" % (info["bvh_build_ms"], t_flat) if info["built_on_device"]
+                       "bvh": "built on the GPU (%s) in %.2f ms (host flatten %.2f s)" % (args.device_bvh, info["bvh_build_ms"], t_flat) if info["built_on_device"]
                               else "built on the host in %.2f s (flatten)" % t_flat},
             "rays_per_step": total_rays, "paths_per_step": total_paths, "node_visits_per_ray": round(st["node_visits"] / max(1, st["rays"]), 2),
             "mpaths_per_s": total_paths * args.steps / elapsed / 1e6,

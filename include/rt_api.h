@@ -130,8 +130,12 @@ typedef struct rt_scene_desc {
        [0, always_begin) are given in any order with one conservative box each (lo xyz, hi xyz) and are re-ordered
        by the build; the always-list must be the tail of the slot array.  bvh_nodes / bvh_root_ref /
        bvh_stack_depth are ignored.  bvh_leaf_max: 1 or 2 slots per leaf, 0 = the library's choice. */
-    const float   *slot_boxes;      uint32_t build_bvh_on_device;   uint32_t bvh_leaf_max;
+    const float   *slot_boxes;      uint32_t build_bvh_on_device;   /* rt_bvh_build */   uint32_t bvh_leaf_max;
 } rt_scene_desc;
+
+/* rt_scene_desc.build_bvh_on_device: who builds the tree.  RT_BVH_DEVICE = parallel locally-ordered clustering over Morton-sorted
+ * leaves (close to the host's SAH tree); RT_BVH_DEVICE_LBVH = Morton radix tree (fastest build, a third more node visits). */
+enum rt_bvh_build { RT_BVH_HOST = 0, RT_BVH_DEVICE = 1, RT_BVH_DEVICE_LBVH = 2 };
 
 /* What rt_scene_upload left on the device (the BVH may have been built there). */
 typedef struct rt_scene_info {

@@ -15,6 +15,13 @@
 //   6. collapse to the 4-wide, 8-bit-quantised nodes of include/rt_api.h: an inner node at even depth adopts
 //      its grandchildren                                                 one thread per inner node + a prefix sum
 //
+// Step 3 has a second form (algo = RT_BVH_DEVICE_PLOC, the default of the device build): parallel locally-ordered
+// clustering (Meister & Bittner 2018) — bottom-up, every cluster looks at its 2 x 32 neighbours in Morton order for the one
+// it makes the smallest box with, mutual choices merge, the survivors are compacted, repeat until one is left (about 30
+// rounds of three small kernels and two prefix sums).  It gives boxes as it goes (no step 5) and a tree close to the host's
+// binned SAH, where Morton splits are a third looser.  Its leaves are then put in depth-first order, so that the two
+// leaves of a pair are neighbours and memory order follows the tree.
+//
 // Which tree the kernels walk changes no result: the closest hit and its tie-break do not depend on the order of
 // the search (rt_kernels.h node4_visit), which is what the parity test of this path checks — images bit-identical to
 // the host-built tree's.  All accesses are HBM streams over arrays of n elements; the build is bandwidth- and
@@ -24,6 +31,7 @@
 
 #include <cfloat>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 
 #include "rt_api.h"
@@ -142,15 +150,17 @@ __global__ void __launch_bounds__(256) depth_kernel(int n_inner, const int2 *chi
 struct Entry { Box6 box; int32_t ref; };
 
 // ref of a child of a 4-wide node: inner node at even depth -> its 4-wide index; a leaf or a pair -> leaf ref
-__device__ __forceinline__ int32_t entry_ref(int c, const int2 *child, const uint32_t *index4, uint32_t leaf_max) {
-    if (c < 0) return ~(int32_t)(((uint32_t)~c << 3) | 0u);
+// (newpos: depth-first position of a leaf; the left leaf of a pair comes first and the right one directly after it)
+__device__ __forceinline__ int32_t entry_ref(int c, const int2 *child, const uint32_t *index4, const uint32_t *newpos, uint32_t leaf_max) {
+    if (c < 0) return ~(int32_t)((newpos[~c] << 3) | 0u);
     const int2 cc = child[c];
-    if (is_pair(cc, leaf_max)) return ~(int32_t)(((uint32_t)~cc.x << 3) | 1u);   // positions ~cc.x and ~cc.x + 1
+    if (is_pair(cc, leaf_max)) return ~(int32_t)((newpos[~cc.x] << 3) | 1u);
     return (int32_t)index4[c];
 }
 
 __global__ void __launch_bounds__(256) emit_kernel(int n_inner, const int2 *child, const float *boxes, const uint32_t *perm, const float *ibox,
-                                                   const uint32_t *is_node4, const uint32_t *index4, uint32_t leaf_max, float *nodes) {
+                                                   const uint32_t *is_node4, const uint32_t *index4, const uint32_t *newpos, uint32_t leaf_max,
+                                                   float *nodes) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n_inner || !is_node4[i]) return;
     Entry e[4];
@@ -161,10 +171,10 @@ __global__ void __launch_bounds__(256) emit_kernel(int n_inner, const int2 *chil
         const int ck = cs[k];
         if (ck >= 0 && !is_pair(child[ck], leaf_max)) {   // an inner node at odd depth: adopt its children
             const int2 g = child[ck];
-            e[n].box = child_box(g.x, boxes, perm, ibox); e[n].ref = entry_ref(g.x, child, index4, leaf_max); ++n;
-            e[n].box = child_box(g.y, boxes, perm, ibox); e[n].ref = entry_ref(g.y, child, index4, leaf_max); ++n;
+            e[n].box = child_box(g.x, boxes, perm, ibox); e[n].ref = entry_ref(g.x, child, index4, newpos, leaf_max); ++n;
+            e[n].box = child_box(g.y, boxes, perm, ibox); e[n].ref = entry_ref(g.y, child, index4, newpos, leaf_max); ++n;
         } else {
-            e[n].box = child_box(ck, boxes, perm, ibox); e[n].ref = entry_ref(ck, child, index4, leaf_max); ++n;
+            e[n].box = child_box(ck, boxes, perm, ibox); e[n].ref = entry_ref(ck, child, index4, newpos, leaf_max); ++n;
         }
     }
     // quantise exactly as the host builder does (rt_host_flatten.cpp): planes on the 8-bit grid of the union box,
@@ -197,10 +207,106 @@ __global__ void __launch_bounds__(256) emit_kernel(int n_inner, const int2 *chil
     for (int k = 0; k < 4; ++k) d[12 + k] = __int_as_float(k < n ? e[k].ref : RT_BVH_EMPTY);
 }
 
+/* ---- PLOC: clusters live in arrays of (box, id); id < 0 = leaf ~position, id >= 0 = inner node ---- */
+
+__device__ __forceinline__ float union_half_area(const float *a, const float *b) {
+    const float dx = fmaxf(a[3], b[3]) - fminf(a[0], b[0]), dy = fmaxf(a[4], b[4]) - fminf(a[1], b[1]), dz = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void __launch_bounds__(256) ploc_init_kernel(const float *__restrict__ boxes, const uint32_t *__restrict__ perm, int n, float *cbox, int *cid) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const float *b = boxes + 6 * (size_t)perm[i];
+    for (int k = 0; k < 6; ++k) cbox[6 * (size_t)i + k] = b[k];
+    cid[i] = ~i;
+}
+
+#define RTB_PLOC_RADIUS 32
+// nearest neighbour of every cluster among the RADIUS before and after it; `pair_up`: neighbours by position (a round in
+// which no two clusters chose each other, possible only with exact area ties, is repeated this way so the loop ends)
+__global__ void __launch_bounds__(256) ploc_nn_kernel(const float *__restrict__ cbox, int c, int pair_up, int radius, int *nn) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= c) return;
+    if (pair_up) { nn[i] = (i ^ 1) < c ? (i ^ 1) : i; return; }
+    float mine[6];
+    for (int k = 0; k < 6; ++k) mine[k] = cbox[6 * (size_t)i + k];
+    const int lo = i - radius < 0 ? 0 : i - radius, hi = i + radius >= c ? c - 1 : i + radius;
+    float best = FLT_MAX;
+    int best_j = i;
+    for (int j = lo; j <= hi; ++j) {
+        if (j == i) continue;
+        const float a = union_half_area(mine, cbox + 6 * (size_t)j);
+        if (a < best || best_j == i) { best = a; best_j = j; }   // ties -> the lower index (also takes a NaN / inf area once)
+    }
+    nn[i] = best_j;
+}
+
+__global__ void __launch_bounds__(256) ploc_flag_kernel(const int *__restrict__ nn, int c, uint32_t *valid, uint32_t *merger) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= c) return;
+    const int j = nn[i];
+    const bool mutual = j != i && nn[j] == i;
+    valid[i] = (!mutual || i < j) ? 1u : 0u;     // the lower one of a pair carries the merged cluster
+    merger[i] = (mutual && i < j) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) ploc_merge_kernel(const float *__restrict__ cbox, const int *__restrict__ cid, const int *__restrict__ nn, int c,
+                                                         const uint32_t *__restrict__ valid, const uint32_t *__restrict__ pos,
+                                                         const uint32_t *__restrict__ merger, const uint32_t *__restrict__ mpos, int node_base,
+                                                         float *cbox_out, int *cid_out, int2 *child, float *ibox, int *parent_inner, int *parent_leaf,
+                                                         uint32_t *leaf_count) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= c || !valid[i]) return;
+    const uint32_t o = pos[i];
+    if (!merger[i]) {
+        for (int k = 0; k < 6; ++k) cbox_out[6 * (size_t)o + k] = cbox[6 * (size_t)i + k];
+        cid_out[o] = cid[i];
+        return;
+    }
+    const int j = nn[i], node = node_base + (int)mpos[i];
+    const int a = cid[i], b = cid[j];
+    float u[6];
+    for (int k = 0; k < 3; ++k) {
+        u[k] = fminf(cbox[6 * (size_t)i + k], cbox[6 * (size_t)j + k]);
+        u[3 + k] = fmaxf(cbox[6 * (size_t)i + 3 + k], cbox[6 * (size_t)j + 3 + k]);
+    }
+    for (int k = 0; k < 6; ++k) { cbox_out[6 * (size_t)o + k] = u[k]; ibox[6 * (size_t)node + k] = u[k]; }
+    cid_out[o] = node;
+    child[node] = make_int2(a, b);
+    if (a >= 0) parent_inner[a] = node; else parent_leaf[~a] = node;
+    if (b >= 0) parent_inner[b] = node; else parent_leaf[~b] = node;
+    leaf_count[node] = (a >= 0 ? leaf_count[a] : 1u) + (b >= 0 ? leaf_count[b] : 1u);
+}
+
+// Depth-first position of every leaf: the leaves of all left siblings on its way to the root come before it.
+__global__ void __launch_bounds__(256) leaf_order_kernel(int n, const int2 *__restrict__ child, const int *__restrict__ parent_inner,
+                                                         const int *__restrict__ parent_leaf, const uint32_t *__restrict__ leaf_count,
+                                                         const uint32_t *__restrict__ sorted_prim, uint32_t *newpos, uint32_t *perm_out) {
+    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (p >= n) return;
+    uint32_t offset = 0;
+    int cur = ~p;
+    for (int node = parent_leaf[p]; node >= 0; node = parent_inner[node]) {
+        const int2 c = child[node];
+        if (c.y == cur) offset += c.x >= 0 ? leaf_count[c.x] : 1u;
+        cur = node;
+    }
+    newpos[p] = offset;
+    perm_out[offset] = sorted_prim[p];
+}
+
+__global__ void __launch_bounds__(256) identity_order_kernel(int n, const uint32_t *__restrict__ sorted_prim, uint32_t *newpos, uint32_t *perm_out) {
+    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (p >= n) return;
+    newpos[p] = (uint32_t)p;
+    perm_out[p] = sorted_prim[p];
+}
+
 }  // namespace
 
-int build_lbvh(hipStream_t stream, const float *d_boxes, uint32_t n, uint32_t leaf_max, const float lo[3], const float hi[3], Result *out,
-               std::string *err) {
+int build_bvh(hipStream_t stream, const float *d_boxes, uint32_t n, uint32_t leaf_max, uint32_t algo, const float lo[3], const float hi[3],
+              Result *out, std::string *err) {
     *out = Result{};
     if (n == 0) { out->root_ref = RT_BVH_EMPTY; out->stack_depth = 1; return RT_OK; }
     if (n >= (1u << 28)) { *err = "too many primitives for the device BVH build"; return RT_E_INVALID; }
@@ -219,8 +325,13 @@ int build_lbvh(hipStream_t stream, const float *d_boxes, uint32_t n, uint32_t le
     size_t sort_bytes = 0, scan_bytes = 0;
     RTB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr,
                                                (uint32_t *)nullptr, (int)n, 0, 63, stream));
-    RTB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, ni > 0 ? ni + 1 : 1, stream));
+    RTB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n + 1, stream));
     const size_t o_tmp = take(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
+    const bool ploc = algo != RT_BVH_DEVICE_LBVH;
+    // PLOC: two cluster arrays (box + id), the neighbour choice, two flag arrays and their prefix sums
+    const size_t o_cb0 = take(ploc ? 24ull * n : 0), o_cb1 = take(ploc ? 24ull * n : 0), o_ci0 = take(ploc ? 4ull * n : 0), o_ci1 = take(ploc ? 4ull * n : 0),
+                 o_nn = take(ploc ? 4ull * n : 0), o_va = take(ploc ? 4ull * (n + 1) : 0), o_vp = take(ploc ? 4ull * (n + 1) : 0),
+                 o_me = take(ploc ? 4ull * (n + 1) : 0), o_mp = take(ploc ? 4ull * (n + 1) : 0);
     char *scratch = nullptr;
     RTB_TRY(hipMalloc((void **)&scratch, off));
     auto done = [&](int rc) { (void)hipFree(scratch); (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return rc; };
@@ -244,17 +355,61 @@ int build_lbvh(hipStream_t stream, const float *d_boxes, uint32_t n, uint32_t le
     uint32_t *perm = nullptr;
     RTB_TRY2(hipMalloc((void **)&perm, 4ull * n));
     out->perm = perm;
-    RTB_TRY2(hipMemcpyAsync(perm, v1, 4ull * n, hipMemcpyDeviceToDevice, stream));
+    const uint32_t *sorted_prim = v1;                 // primitive at Morton position p
+    uint32_t *newpos = (uint32_t *)k0;                // (the unsorted keys and values are not needed any more)
+    uint32_t *leaf_count = v0;
     if (n == 1 || (n == 2 && leaf_max >= 2u)) {   // the whole scene is one leaf
+        RTB_TRY2(hipMemcpyAsync(perm, v1, 4ull * n, hipMemcpyDeviceToDevice, stream));
         out->root_ref = ~(int32_t)((0u << 3) | (n - 1u));
         out->stack_depth = 1;
     } else {
         RTB_TRY2(hipMemsetAsync(max_depth, 0, 4, stream));
-        hipLaunchKernelGGL(radix_tree_kernel, dim3(gi), dim3(256), 0, stream, k1, (int)n, child, parent_inner, parent_leaf);
+        int root = 0;
+        if (!ploc) {
+            hipLaunchKernelGGL(radix_tree_kernel, dim3(gi), dim3(256), 0, stream, k1, (int)n, child, parent_inner, parent_leaf);
+            hipLaunchKernelGGL(identity_order_kernel, dim3(gn), dim3(256), 0, stream, (int)n, sorted_prim, newpos, perm);
+        } else {
+            float *cb[2] = {(float *)(scratch + o_cb0), (float *)(scratch + o_cb1)};
+            int *ci[2] = {(int *)(scratch + o_ci0), (int *)(scratch + o_ci1)};
+            int *nn = (int *)(scratch + o_nn);
+            auto *valid = (uint32_t *)(scratch + o_va), *vpos = (uint32_t *)(scratch + o_vp), *merger = (uint32_t *)(scratch + o_me), *mpos = (uint32_t *)(scratch + o_mp);
+            hipLaunchKernelGGL(ploc_init_kernel, dim3(gn), dim3(256), 0, stream, d_boxes, sorted_prim, (int)n, cb[0], ci[0]);
+            int c = (int)n, node_base = 0, cur = 0, pair_up = 0, radius = RTB_PLOC_RADIUS;
+            if (const char *e = getenv("RT_BVH_PLOC_RADIUS")) { const int v = atoi(e); if (v >= 1 && v <= 256) radius = v; }
+            for (int round = 0; c > 1; ++round) {
+                if (round > 4096) { *err = "device BVH build: clustering does not converge"; return done(RT_E_HIP); }
+                const unsigned gc = ((unsigned)c + 255u) / 256u;
+                hipLaunchKernelGGL(ploc_nn_kernel, dim3(gc), dim3(256), 0, stream, cb[cur], c, pair_up, radius, nn);
+                hipLaunchKernelGGL(ploc_flag_kernel, dim3(gc), dim3(256), 0, stream, nn, c, valid, merger);
+                RTB_TRY2(hipMemsetAsync(valid + c, 0, 4, stream));    // the sums run over c + 1 flags: the last output is the total
+                RTB_TRY2(hipMemsetAsync(merger + c, 0, 4, stream));
+                RTB_TRY2(hipcub::DeviceScan::ExclusiveSum(scratch + o_tmp, scan_bytes, valid, vpos, c + 1, stream));
+                RTB_TRY2(hipcub::DeviceScan::ExclusiveSum(scratch + o_tmp, scan_bytes, merger, mpos, c + 1, stream));
+                uint32_t tot[2] = {0, 0};
+                RTB_TRY2(hipMemcpyAsync(&tot[0], vpos + c, 4, hipMemcpyDeviceToHost, stream));
+                RTB_TRY2(hipMemcpyAsync(&tot[1], mpos + c, 4, hipMemcpyDeviceToHost, stream));
+                RTB_TRY2(hipStreamSynchronize(stream));
+                if (tot[1] == 0u) {                                    // nobody chose each other (exact ties): pair neighbours up once
+                    if (pair_up) { *err = "device BVH build: clustering made no progress"; return done(RT_E_HIP); }
+                    pair_up = 1;
+                    continue;
+                }
+                if ((int)tot[0] != c - (int)tot[1] || node_base + (int)tot[1] > ni) { *err = "device BVH build: inconsistent clustering"; return done(RT_E_HIP); }
+                hipLaunchKernelGGL(ploc_merge_kernel, dim3(gc), dim3(256), 0, stream, cb[cur], ci[cur], nn, c, valid, vpos, merger, mpos, node_base, cb[cur ^ 1],
+                                   ci[cur ^ 1], child, ibox, parent_inner, parent_leaf, leaf_count);
+                cur ^= 1; c = (int)tot[0]; node_base += (int)tot[1]; pair_up = 0;
+                out->rounds += 1;
+            }
+            if (node_base != ni) { *err = "device BVH build: clustering lost nodes"; return done(RT_E_HIP); }
+            root = ni - 1;                               // the last merge
+            RTB_TRY2(hipMemsetAsync(parent_inner + root, 0xff, 4, stream));   // -1
+            hipLaunchKernelGGL(leaf_order_kernel, dim3(gn), dim3(256), 0, stream, (int)n, child, parent_inner, parent_leaf, leaf_count, sorted_prim, newpos, perm);
+        }
         hipLaunchKernelGGL(depth_kernel, dim3(gi), dim3(256), 0, stream, ni, child, parent_inner, leaf_max, depth, is4, max_depth);
         RTB_TRY2(hipMemsetAsync(is4 + ni, 0, 4, stream));   // the scan runs over ni + 1 flags: its last output is the node count
         RTB_TRY2(hipcub::DeviceScan::ExclusiveSum(scratch + o_tmp, scan_bytes, is4, ix4, ni + 1, stream));
-        uint32_t h[2] = {0, 0};
+        uint32_t h[3] = {0, 0, 0};
+        RTB_TRY2(hipMemcpyAsync(&h[2], ix4 + root, 4, hipMemcpyDeviceToHost, stream));
         RTB_TRY2(hipMemcpyAsync(&h[0], ix4 + ni, 4, hipMemcpyDeviceToHost, stream));
         RTB_TRY2(hipMemcpyAsync(&h[1], max_depth, 4, hipMemcpyDeviceToHost, stream));
         RTB_TRY2(hipStreamSynchronize(stream));
@@ -265,10 +420,10 @@ int build_lbvh(hipStream_t stream, const float *d_boxes, uint32_t n, uint32_t le
         out->nodes = nodes;
         out->n_nodes = n4;
         if (h[1] >= 4096u) { *err = "device BVH build: implausible tree depth"; return done(RT_E_HIP); }
-        for (uint32_t level = h[1] + 1u; level-- > 0u;)
-            hipLaunchKernelGGL(fit_level_kernel, dim3(gi), dim3(256), 0, stream, d_boxes, perm, ni, child, depth, level, ibox);
-        hipLaunchKernelGGL(emit_kernel, dim3(gi), dim3(256), 0, stream, ni, child, d_boxes, perm, ibox, is4, ix4, leaf_max, nodes);
-        out->root_ref = 0;                       // inner node 0 is the root (depth 0) and the first flag of the scan
+        for (uint32_t level = h[1] + 1u; !ploc && level-- > 0u;)   // (the clustering made its boxes as it went)
+            hipLaunchKernelGGL(fit_level_kernel, dim3(gi), dim3(256), 0, stream, d_boxes, sorted_prim, ni, child, depth, level, ibox);
+        hipLaunchKernelGGL(emit_kernel, dim3(gi), dim3(256), 0, stream, ni, child, d_boxes, sorted_prim, ibox, is4, ix4, newpos, leaf_max, nodes);
+        out->root_ref = (int32_t)h[2];           // the root is at depth 0, hence a 4-wide node
         out->stack_depth = 3u * (h[1] / 2u + 1u) + 2u;   // a visit pushes at most three children
     }
     RTB_TRY2(hipGetLastError());

@@ -359,6 +359,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         if (s->always_begin + s->always_count != s->n_slots) return fail(ctx, RT_E_INVALID, "device BVH build: the always-list must be the tail of the slot array");
         if (s->always_begin && !s->slot_boxes) return fail(ctx, RT_E_INVALID, "device BVH build: slot_boxes missing");
         if (s->bvh_leaf_max > 2) return fail(ctx, RT_E_INVALID, "bvh_leaf_max %u: 0, 1 or 2", s->bvh_leaf_max);
+        if (s->build_bvh_on_device > RT_BVH_DEVICE_LBVH) return fail(ctx, RT_E_INVALID, "build_bvh_on_device %u: unknown builder", s->build_bvh_on_device);
     } else if (s->bvh_stack_depth == 0 || s->bvh_stack_depth > kMaxStackDepth)
         return fail(ctx, RT_E_INVALID, "bvh_stack_depth %u out of range", s->bvh_stack_depth);
     auto ref_ok = [&](int32_t ref) {
@@ -501,7 +502,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         rtb::Result res;
         std::string err;
         const uint32_t leaf_max = s->bvh_leaf_max ? s->bvh_leaf_max : (nb >= 100000u ? 2u : 1u);   // as the host builder chooses
-        st = rtb::build_lbvh(ctx->stream, d_boxes, nb, leaf_max, lo, hi, &res, &err);
+        st = rtb::build_bvh(ctx->stream, d_boxes, nb, leaf_max, s->build_bvh_on_device, lo, hi, &res, &err);
         if (res.nodes) own.push_back(res.nodes);
         if (res.perm) tmp.push_back(res.perm);
         if (st != RT_OK) return cleanup(fail(ctx, st, "device BVH build: %s", err.c_str()));

@@ -31,7 +31,10 @@ def device_tree(gpu, flat):
     return types.SimpleNamespace(nodes=lambda: nodes, slots=lambda: slots, desc=desc), info
 
 
-def both_trees(rt, gpu, scene, params, camera, sampler, n_rays, leaf_max=0, expect_boxes=False):
+PLOC, LBVH = 1, 2     # rt_bvh_build: RT_BVH_DEVICE (clustering), RT_BVH_DEVICE_LBVH (Morton radix tree)
+
+
+def both_trees(rt, gpu, scene, params, camera, sampler, n_rays, leaf_max=0, expect_boxes=False, algo=PLOC):
     rays = primary_and_bounce_rays(rt, scene, params, camera, n_rays)
     host_flat = scene.flatten()
     gpu.upload_scene(host_flat)
@@ -43,6 +46,7 @@ def both_trees(rt, gpu, scene, params, camera, sampler, n_rays, leaf_max=0, expe
     dev_flat = scene.flatten(device_bvh=True)
     assert dev_flat.desc.build_bvh_on_device == 1 and dev_flat.desc.n_bvh_nodes == 0
     dev_flat.desc.bvh_leaf_max = leaf_max
+    dev_flat.desc.build_bvh_on_device = algo
     gpu.upload_scene(dev_flat)
     tree, info = device_tree(gpu, dev_flat)
     assert info["built_on_device"] == 1 and info["n_bvh_nodes"] > 0 and info["bvh_build_ms"] > 0.0
@@ -56,28 +60,31 @@ def both_trees(rt, gpu, scene, params, camera, sampler, n_rays, leaf_max=0, expe
     return info, st_host, st_dev
 
 
+@pytest.mark.parametrize("algo", [PLOC, LBVH])
 @pytest.mark.parametrize("name,width,spp,extra,leaf_max", [
     ("C1", 160, 9, {}, 0),                      # moving spheres: the moving-slot list is translated to the new order
     ("C3", 96, 9, {}, 0),                       # blocks, Translate(RotateY) spheres, media; the rect list
     ("C3", 64, 4, {}, 2),                       # pairs of slots per leaf
     ("C4", 64, 4, {"mesh_grid": 2}, 2),         # 90 584 triangles: attributes are gathered with the slots
 ])
-def test_device_built_tree_renders_the_same_bits(rt, gpu, name, width, spp, extra, leaf_max):
+def test_device_built_tree_renders_the_same_bits(rt, gpu, name, width, spp, extra, leaf_max, algo):
     scene, params, camera, sampler = rt.configs.build(name, image_width=width, samples_per_pixel=spp, **extra)
-    info, st_host, st_dev = both_trees(rt, gpu, scene, params, camera, sampler, 1 << 14, leaf_max, expect_boxes=(name == "C1"))
-    # Morton splits make a looser tree than binned SAH: more node visits for the same hits, within reason
-    assert st_dev["node_visits"] < 4 * st_host["node_visits"]
+    info, st_host, st_dev = both_trees(rt, gpu, scene, params, camera, sampler, 1 << 14, leaf_max, expect_boxes=(name == "C1"), algo=algo)
+    # Morton splits make a looser tree than binned SAH (more node visits for the same hits); the clustering stays close to it
+    assert st_dev["node_visits"] < (4 if algo == LBVH else 2) * st_host["node_visits"]
 
 
 def test_device_build_next_to_an_always_list(rt, gpu):
     scene, params = quadric_playground(rt)
     sampler = rt.host.MultiJitteredSampler(params.samples_per_pixel)
-    info, _, _ = both_trees(rt, gpu, scene, params, params.camera(), sampler, 1 << 13)
-    assert info["n_slots"] == 31 + 15
+    for algo in (PLOC, LBVH):
+        info, _, _ = both_trees(rt, gpu, scene, params, params.camera(), sampler, 1 << 13, algo=algo)
+        assert info["n_slots"] == 31 + 15
 
 
 def test_coincident_centres_and_tiny_inputs(rt, gpu):
-    """Equal Morton codes are split by position (Karras 2012, sec. 4): 40 concentric spheres plus 24 in a row."""
+    """Equal Morton codes are split by position (Karras 2012, sec. 4), equal merge costs fall back to pairing neighbours:
+    40 concentric spheres plus 24 identical ones in a row."""
     s = rt.host.Scene()
     m = s.lambertian(s.solid(0.5, 0.5, 0.5))
     objs = [s.sphere((0, 0, 0), 0.1 * (i + 1), s.dielectric(1.5)) for i in range(40)]
@@ -88,11 +95,13 @@ def test_coincident_centres_and_tiny_inputs(rt, gpu):
         background=(0.5, 0.6, 0.8))
     sampler = rt.host.MultiJitteredSampler(4)
     for leaf_max in (1, 2):
-        both_trees(rt, gpu, s, params, params.camera(), sampler, 1 << 12, leaf_max)
+        for algo in (PLOC, LBVH):
+            both_trees(rt, gpu, s, params, params.camera(), sampler, 1 << 12, leaf_max, algo=algo)
     # 17 primitives: the smallest scene that gets a tree at all
     s2 = rt.host.Scene()
     m2 = s2.lambertian(s2.solid(0.5, 0.5, 0.5))
     objs = [s2.sphere((float(i), 0, 0), 0.4, m2) for i in range(17)]
     s2.set_roots(s2.hittable_list(objs), s2.hittable_list([s2.xz_rect(-1, 1, -1, 1, 9, s2.diffuse_light(s2.solid(0, 0, 0)))]))
     p2 = params.replace(look_from=(8.0, 2.0, 20.0), look_at=(8.0, 0.0, 0.0))
-    both_trees(rt, gpu, s2, p2, p2.camera(), sampler, 1 << 12, 2)
+    for algo in (PLOC, LBVH):
+        both_trees(rt, gpu, s2, p2, p2.camera(), sampler, 1 << 12, 2, algo=algo)

@@ -3,7 +3,7 @@
 TAG=$1
 rm -f gpurun_out/bench_bvh_$TAG.jsonl
 for w in "C1 100" "C3 128" "C4 32"; do set -- $w
-  for mode in "" "--device-bvh"; do
+  for mode in "" "--device-bvh=ploc" "--device-bvh=lbvh"; do
     timeout -k 10 300 python -u bench.py --steps 2 --warmup 1 --no-cpu --workload $1 --spp $2 $mode >> gpurun_out/bench_bvh_$TAG.jsonl 2>> gpurun_out/bench_bvh_$TAG.err || exit 1
   done
 done
