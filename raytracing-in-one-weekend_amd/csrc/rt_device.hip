@@ -498,6 +498,10 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         const float *d_boxes = nullptr;
         std::vector<void *> tmp;
         auto cleanup = [&](int rc) { (void)hipStreamSynchronize(ctx->stream); free_all(tmp); return rc; };
+        auto retire = [&](const void *p) {   // scene_allocs -> tmp
+            for (size_t k = 0; k < own.size(); ++k)
+                if (own[k] == p) { tmp.push_back(own[k]); own.erase(own.begin() + (long)k); return; }
+        };
         if ((st = upload(ctx, tmp, s->slot_boxes, (size_t)nb * 24, &d_boxes)) != RT_OK) return cleanup(st);
         rtb::Result res;
         std::string err;
@@ -516,13 +520,15 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
             if (s->always_count)
                 HIP_TRY_C(hipMemcpyAsync(const_cast<float4 *>(sorted_slots) + 4 * (size_t)nb, d.slots + 4 * (size_t)nb, (size_t)s->always_count * RT_SLOT_FLOATS * 4,
                                          hipMemcpyDeviceToDevice, ctx->stream));
-            d.slots = sorted_slots;   // the unsorted copy stays in scene_allocs until the next upload
+            retire(d.slots);          // the unsorted copy goes when the gathers are done (cleanup)
+            d.slots = sorted_slots;
             if (tris) {
                 if ((st = upload(ctx, own, nullptr, (size_t)s->n_slots * RT_ATTR_FLOATS * 4, &sorted_attrs)) != RT_OK) return cleanup(st);
                 rtb::gather_records(ctx->stream, d.attrs, res.perm, nb, RT_ATTR_FLOATS, const_cast<float4 *>(sorted_attrs));
                 if (s->always_count)
                     HIP_TRY_C(hipMemcpyAsync(const_cast<float4 *>(sorted_attrs) + 4 * (size_t)nb, d.attrs + 4 * (size_t)nb, (size_t)s->always_count * RT_ATTR_FLOATS * 4,
                                              hipMemcpyDeviceToDevice, ctx->stream));
+                retire(d.attrs);
                 d.attrs = sorted_attrs;
             }
             if ((st = upload(ctx, tmp, nullptr, (size_t)nb * 4, &inv)) != RT_OK) return cleanup(st);
