@@ -213,10 +213,8 @@ RT_DEV V3 moving_center(float4 q0, float time0, float4 q2, float time) {  // sph
 RT_DEV float comp(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
 
 // rectangles.rs:22-34 / 92-104 / 162-174.  type: 2 XY (A=x,B=y,AX=z) 3 XZ (x,z,y) 4 YZ (y,z,x)
-RT_DEV bool rect_test(int type, float4 q0, float k, const Ray &r, float t_min, float t_max, float *t_out, float *a_out, float *b_out) {
-    int AX = type == RT_PRIM_XY_RECT ? 2 : (type == RT_PRIM_XZ_RECT ? 1 : 0);
-    int A = type == RT_PRIM_YZ_RECT ? 1 : 0;
-    int B = type == RT_PRIM_XY_RECT ? 1 : 2;
+template <int AX, int A, int B>
+RT_DEV bool rect_test_axes(float4 q0, float k, const Ray &r, float t_min, float t_max, float *t_out, float *a_out, float *b_out) {
     float t = (k - comp(r.o, AX)) / comp(r.d, AX);
     if (t < t_min || t > t_max) return false;
     float a = comp(r.o, A) + t * comp(r.d, A);
@@ -224,6 +222,12 @@ RT_DEV bool rect_test(int type, float4 q0, float k, const Ray &r, float t_min, f
     if (a < q0.x || a > q0.y || b < q0.z || b > q0.w) return false;
     *t_out = t; *a_out = a; *b_out = b;
     return true;
+}
+// (one instantiation per kind: the kind is wave-uniform in the always-list, so the axes cost a scalar branch instead of selects)
+RT_DEV bool rect_test(int type, float4 q0, float k, const Ray &r, float t_min, float t_max, float *t_out, float *a_out, float *b_out) {
+    if (type == RT_PRIM_XY_RECT) return rect_test_axes<2, 0, 1>(q0, k, r, t_min, t_max, t_out, a_out, b_out);
+    if (type == RT_PRIM_XZ_RECT) return rect_test_axes<1, 0, 2>(q0, k, r, t_min, t_max, t_out, a_out, b_out);
+    return rect_test_axes<0, 1, 2>(q0, k, r, t_min, t_max, t_out, a_out, b_out);
 }
 
 struct TriHit {
