@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) depth_kernel(int n_inner, const int2 *chi
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     uint32_t depth = 0;
     if (i < n_inner) {   // (no early return: every lane of the wave takes part in the reduction below)
-        for (int p = parent_inner[i]; p >= 0; p = parent_inner[p]) ++depth;
+        for (int p = parent_inner[i]; p >= 0 && depth < 4096u; p = parent_inner[p]) ++depth;   // (bounded: the host refuses depth >= 4096)
         depth_out[i] = depth;
         is_node4[i] = ((depth & 1u) == 0u && !is_pair(child[i], leaf_max)) ? 1u : 0u;
     }
@@ -287,11 +287,13 @@ __global__ void __launch_bounds__(256) leaf_order_kernel(int n, const int2 *__re
     if (p >= n) return;
     uint32_t offset = 0;
     int cur = ~p;
-    for (int node = parent_leaf[p]; node >= 0; node = parent_inner[node]) {
+    int guard = 0;   // a tree deeper than this is refused by the host afterwards; the bound keeps a broken one from hanging the wave
+    for (int node = parent_leaf[p]; node >= 0 && guard < 8192; node = parent_inner[node], ++guard) {
         const int2 c = child[node];
         if (c.y == cur) offset += c.x >= 0 ? leaf_count[c.x] : 1u;
         cur = node;
     }
+    if (offset >= (uint32_t)n) offset = (uint32_t)p;   // only with a broken tree; stay inside the arrays
     newpos[p] = offset;
     perm_out[offset] = sorted_prim[p];
 }
