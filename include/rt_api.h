@@ -125,7 +125,7 @@ typedef struct rt_scene_desc {
                                        hit test can ACCEPT a NaN distance for a finite ray (0/0 when the ray lies in the
                                        plane, rectangles.rs:23-34); scanned when a direction component is exactly 0 */
     uint32_t       n_prims;         /* number of primitive ids in the scene */
-    const float   *matrices;        uint32_t n_matrices;     /* RT_MATRIX_FLOATS each; slots under one are in the always-list */
+    const float   *matrices;        uint32_t n_matrices;     /* RT_MATRIX_FLOATS each */
     /* Build the BVH on the GPU instead of taking bvh_nodes (rt_bvh_build.hip): slots
        [0, always_begin) are given in any order with one conservative box each (lo xyz, hi xyz) and are re-ordered
        by the build; the always-list must be the tail of the slot array.  bvh_nodes / bvh_root_ref /

@@ -29,6 +29,7 @@ struct rt_ctx {
     bool have_scene = false, have_sampler = false;
     uint32_t stack_depth = 1;
     uint32_t n_bvh_nodes = 0, built_on_device = 0;
+    bool bvh_has_general_xform = false;   // some slot under a general Transform sits in a BVH leaf
     float bvh_build_ms = 0.0f;
     unsigned long long *d_stats = nullptr;  // 64 counters
     hipDeviceProp_t prop{};
@@ -170,10 +171,12 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     const uint32_t lds_depth = lds_want < ctx->stack_depth ? lds_want : ctx->stack_depth;
     const size_t lds = (size_t)lds_depth * 256 * sizeof(StackEntry);
     int per_cu = 0;
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_traverse_kernel<STATS>, 256, lds));
+    // two instances of the traversal kernel: scenes with a general Transform inside the BVH need the code for it in the leaf step
+    auto *const trav_kernel = ctx->bvh_has_general_xform ? wf_traverse_kernel<STATS, EXT_XFORM> : wf_traverse_kernel<STATS, EXT_NONE>;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel, 256, lds));
     {   // the runtime's answer may assume the 64 KB per-workgroup LDS limit; gfx950 has 160 KB per CU
         hipFuncAttributes fa{};
-        HIP_TRY(ctx, hipFuncGetAttributes(&fa, (const void *)wf_traverse_kernel<STATS>));
+        HIP_TRY(ctx, hipFuncGetAttributes(&fa, (const void *)trav_kernel));
         int regs = fa.numRegs > 0 ? (fa.numRegs + 7) / 8 * 8 : 128;
         int by_regs = 512 / regs > 8 ? 8 : 512 / regs;
         int by_lds = lds ? (int)((160 * 1024) / lds) : 8;
@@ -257,7 +260,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                 for (int k = 0; k < 8; ++k) {
                     const uint32_t it = ++P.it;
                     const PathQ &cur = P.Q[it & 1], &nxt = P.Q[(it + 1) & 1];
-                    if (has_bvh) hipLaunchKernelGGL(wf_traverse_kernel<STATS>, dim3(trav_blocks), dim3(256), lds, P.s, ctx->sc, cur, P.ctr, it, P.w.cap,
+                    if (has_bvh) hipLaunchKernelGGL(trav_kernel, dim3(trav_blocks), dim3(256), lds, P.s, ctx->sc, cur, P.ctr, it, P.w.cap,
                                                     lds_depth, P.ovf, d_stats);
                     hipLaunchKernelGGL(wf_shade_kernel<STATS>, dim3(P.pool_blocks), dim3(256), 0, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
                                        ctx->wf_samples, d_stats, d_rays);
@@ -375,7 +378,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         for (int32_t r : refs)
             if (!ref_ok(r)) return fail(ctx, RT_E_INVALID, "bvh node %u has a child out of range", i);
     }
-    bool tris = false;
+    bool tris = false, general_in_bvh = false;
     for (uint32_t i = 0; i < s->n_slots; ++i) {
         int32_t w4, mat;
         memcpy(&w4, &s->slots[i * RT_SLOT_FLOATS + 4], 4);
@@ -391,9 +394,10 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
             general = (flags & 4) != 0;
             if (general && (m < 0 || (uint32_t)m >= s->n_matrices || !s->matrices)) return fail(ctx, RT_E_INVALID, "slot %u: matrix out of range", i);
         }
-        // the traversal kernel does not carry the code for these (rt_kernels.h slot_hit_rec<STATS, false>)
-        if ((general || type >= RT_PRIM_CYLINDER) && !(i >= s->always_begin && i - s->always_begin < s->always_count))
-            return fail(ctx, RT_E_INVALID, "slot %u: quadrics and slots under a general Transform must be in the always-list", i);
+        const bool in_always = i >= s->always_begin && i - s->always_begin < s->always_count;
+        // quadrics may accept hits below t_min (cone.rs:61-65): the traversal kernels do not carry their code
+        if (type >= RT_PRIM_CYLINDER && !in_always) return fail(ctx, RT_E_INVALID, "slot %u: quadrics must be in the always-list", i);
+        general_in_bvh |= general && !in_always;
         if (mat < 0 || (uint32_t)mat >= s->n_materials) return fail(ctx, RT_E_INVALID, "slot %u: material out of range", i);
         tris |= type == RT_PRIM_TRIANGLE;
     }
@@ -483,6 +487,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     ctx->stack_depth = s->bvh_stack_depth;
     ctx->n_bvh_nodes = s->n_bvh_nodes;
     ctx->built_on_device = 0;
+    ctx->bvh_has_general_xform = general_in_bvh;
     ctx->bvh_build_ms = 0.0f;
     if (device_build) {
         // Morton order decides where a slot goes: build over the boxes, then gather slots and triangle attributes into

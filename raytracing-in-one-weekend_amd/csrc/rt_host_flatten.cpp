@@ -142,7 +142,7 @@ struct Flattener {
         float pad = 1.0e-4f * m;
         for (int a = 0; a < 3; ++a) { wb.lo[a] -= pad; wb.hi[a] += pad; }
         prims.push_back(s);
-        always.push_back((type >= RT_PRIM_CYLINDER || w.matrix >= 0) ? 1 : 0);
+        always.push_back(type >= RT_PRIM_CYLINDER ? 1 : 0);   // quadrics may accept t < t_min (cone.rs:61-65): no box test for them
         Attr a{};
         if (attr) a = *attr;
         pattrs.push_back(a);
@@ -516,7 +516,9 @@ int rth_flatten_opts(const rtg_graph *g, uint32_t flags, rth_flat **out_flat) {
     std::vector<uint32_t> in_bvh, in_always;   // primitive indices
     for (size_t i = 0; i < n_all; ++i) (fl.always[i] ? in_always : in_bvh).push_back((uint32_t)i);
     const size_t n = in_bvh.size();
-    if (n <= 16) {  // tiny scenes (Cornell box: 13 leaves): a flat scan beats any tree
+    size_t flat_max = 24;   // measured on MI355X: Cornell box (13 leaves) and Blocks (20) are faster as a flat scan (Blocks: 10.5 vs 9.1 Grays/s)
+    if (const char *e = getenv("RTH_FLAT_MAX")) { int v = atoi(e); if (v >= 0 && v <= 4096) flat_max = (size_t)v; }
+    if (n <= flat_max) {  // tiny scenes (Cornell box: 13 leaves): a flat scan beats any tree
         flat->slots = fl.prims;
         flat->attrs = fl.pattrs;
         std::iota(new_index.begin(), new_index.end(), 0u);

@@ -147,14 +147,16 @@ RT_DEV float mat_row(float4 m, V3 v, float w) { return m.x * v.x + m.y * v.y + m
 RT_DEV V3 mat_apply(const float4 *m, V3 v, float w) { return v3(mat_row(m[0], v, w), mat_row(m[1], v, w), mat_row(m[2], v, w)); }
 
 // Ray into the frame of a wrapped primitive: Translate (transform.rs:34) then RotateY (:117-126), or a general
-// Transform (transform.rs:190 + math/src/ray.rs:42-54).  EXT = false leaves the general Transform out: slots
-// under one are never reached through the BVH (rt_api.h), so the traversal kernel does not carry the code.
-template <bool EXT = true>
+// Transform (transform.rs:190 + math/src/ray.rs:42-54).  EXT selects what is compiled in: bit 0 the general Transform,
+// bit 1 the quadrics.  The traversal kernel exists without either (scenes with no general Transform in the BVH keep the
+// smaller code) and with the Transform; quadrics are never reached through the BVH (rt_api.h).
+enum { EXT_NONE = 0, EXT_XFORM = 1, EXT_QUADRICS = 2, EXT_ALL = 3 };
+template <int EXT = EXT_ALL>
 RT_DEV Ray to_object_rec(const DScene &sc, float4 a, float4 b, const Ray &r) {
     int flags = f2i(a.x);
     float sin_t = a.y, cos_t = a.z;
     Ray q = r;
-    if (EXT && (flags & 4)) {
+    if ((EXT & EXT_XFORM) && (flags & 4)) {
         const float4 *m = sc.matrices + 9 * (size_t)f2i(a.y);
         q.o = mat_apply(m, r.o, 1.0f);
         q.d = mat_apply(m, r.d, 0.0f);
@@ -170,7 +172,7 @@ RT_DEV Ray to_object_rec(const DScene &sc, float4 a, float4 b, const Ray &r) {
     }
     return q;
 }
-template <bool EXT = true>
+template <int EXT = EXT_ALL>
 RT_DEV Ray to_object(const DScene &sc, int xf, const Ray &r) { return to_object_rec<EXT>(sc, sc.xforms[2 * xf], sc.xforms[2 * xf + 1], r); }
 
 // A slot as the kernels read it: all 64 bytes at once, so that the loads of a test do not wait on
@@ -392,8 +394,8 @@ RT_DEV V3 quadric_record(int type, const SlotRec &s, const QuadHit &h, float *u,
 }
 
 // Hit test of one slot: true + t when `obj.hit(r, t_min, t_max)` of that leaf would return Some.
-// EXT = false: without the quadrics and the general Transform (see to_object_rec).
-template <bool STATS, bool EXT = true>
+// EXT: see to_object_rec.
+template <bool STATS, int EXT = EXT_ALL>
 RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, const Ray &r_world, float t_min, float t_max, float *t_out,
                          int32_t *id_out, Counters &cnt, const Ray *r_object = nullptr /* the ray already in the slot's frame */) {
     const float4 q0 = s.q0, meta = s.meta;
@@ -405,7 +407,7 @@ RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, cons
     Ray r = r_world;
     if (r_object) r = *r_object;
     else if (xf >= 0) r = type_has_inline_xform(type) ? to_object_rec<EXT>(sc, s.q2, s.q3, r_world) : to_object<EXT>(sc, xf, r_world);
-    if (EXT && type >= RT_PRIM_CYLINDER) {
+    if ((EXT & EXT_QUADRICS) && type >= RT_PRIM_CYLINDER) {
         QuadHit qh;
         if (!quadric_test(type, s, r, t_min, t_max, &qh)) return false;
         *t_out = qh.t;
@@ -428,7 +430,7 @@ RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, cons
     }
     }
 }
-template <bool STATS, bool EXT = true>
+template <bool STATS, int EXT = EXT_ALL>
 RT_DEV bool slot_hit(const DScene &sc, uint32_t slot, const Ray &r_world, float t_min, float t_max, float *t_out, int32_t *id_out,
                      Counters &cnt) {
     return slot_hit_rec<STATS, EXT>(sc, slot, load_slot(sc, slot), r_world, t_min, t_max, t_out, id_out, cnt);
@@ -634,7 +636,7 @@ RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_
         for (uint32_t i = 0; i < count; ++i) {
             float t;
             int32_t id;
-            if (slot_hit<STATS, false>(sc, first + i, r, t_min, best.t, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)(first + i));
+            if (slot_hit<STATS, EXT_XFORM>(sc, first + i, r, t_min, best.t, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)(first + i));
         }
         ref = pop_ref(stack, sp);
     }
@@ -848,14 +850,14 @@ RT_DEV void trav_node_step(const DScene &sc, float t_min, Trav &tv, const Stack 
     tv.ref = node4_visit(sc, tv.ref, tv.inv, tv.oi, t_min, tv.best.t, stack, tv.sp);
 }
 
-template <bool STATS>
+template <bool STATS, int EXT>
 RT_DEV void trav_leaf_step(const DScene &sc, const Ray &r, float t_min, Trav &tv, const Stack &stack, Counters &cnt) {
     uint32_t code = (uint32_t)~tv.ref;
     uint32_t first = code >> 3, count = (code & 7u) + 1u;
     for (uint32_t i = 0; i < count; ++i) {
         float t;
         int32_t id;
-        if (slot_hit<STATS, false>(sc, first + i, r, t_min, tv.best.t, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)(first + i));
+        if (slot_hit<STATS, EXT>(sc, first + i, r, t_min, tv.best.t, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)(first + i));
     }
     tv.ref = pop_ref(stack, tv.sp);
 }

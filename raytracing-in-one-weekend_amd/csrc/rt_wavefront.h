@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256) wf_generate_kernel(DScene sc, WfArgs w, P
 #ifndef RT_WF_TRAV_WAVES
 #define RT_WF_TRAV_WAVES 6      // min waves per SIMD the traverse kernel is compiled for (80 VGPRs, no spills)
 #endif
-template <bool STATS>
+template <bool STATS, int EXT>
 __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DScene sc, PathQ q, WfCounters *ctr, uint32_t it, uint32_t cap, uint32_t lds_depth,
                                                           StackEntry *ovf, unsigned long long *stats) {
     extern __shared__ StackEntry lds_stack[];
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
         if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
             phase_count<STATS>(cnt, PH_LEAF, at_leaf);
             RG_BEGIN(RG_LEAF);
-            if (at_leaf) trav_leaf_step<STATS>(sc, r, T_MIN, tv, stack, cnt);
+            if (at_leaf) trav_leaf_step<STATS, EXT>(sc, r, T_MIN, tv, stack, cnt);
             RG_END(RG_LEAF);
         }
         if (idx >= 0 && tv.ref == RT_BVH_EMPTY) {

@@ -211,11 +211,11 @@ def quadric_playground(rt):
 
 
 def test_quadrics_and_transforms_next_to_a_bvh(rt, gpu):
-    """Quadrics and slots under a general Transform live in the always-list (they may accept t < t_min, cone.rs:61-65)
-    while everything else goes through the BVH."""
+    """Quadrics live in the always-list (they may accept t < t_min, cone.rs:61-65) while everything else, slots under a
+    general Transform included, goes through the BVH."""
     s, params = quadric_playground(rt)
     flat = s.flatten()
-    assert flat.desc.n_bvh_nodes > 0 and flat.desc.always_count == 7 + 6 + 1 + 1
+    assert flat.desc.n_bvh_nodes > 0 and flat.desc.always_count == 7        # the quadrics; block, light and glass ball under their Transforms are BVH leaves
     camera = params.camera()
     sampler = rt.host.MultiJitteredSampler(16)
     gpu.upload_scene(flat)
@@ -229,3 +229,52 @@ def test_quadrics_and_transforms_next_to_a_bvh(rt, gpu):
     assert len(quadric_ids & set(g[0][hit].tolist())) == 7, "every quadric must be seen by some ray"
     check_first_hit(gpu, oracle, bounce_rays(rays, g[1], g[2], hit))
     compare_images(rt, gpu, oracle, params, camera, sampler)
+
+
+def test_many_transformed_blocks_go_through_the_bvh(rt, gpu):
+    """48 blocks and 12 spheres, each under its own general Transform (rotation about a random axis, non-uniform scale):
+    368 leaves in the BVH, none in the always-list; the second instance of the traversal kernel (with the Transform code)."""
+    rng = np.random.default_rng(9)
+    s = rt.host.Scene()
+    grey = s.lambertian(s.checker(s.solid(0.2, 0.3, 0.1), s.solid(0.9, 0.9, 0.9), 2.0))
+    objs = [s.xz_rect(-1000, 1000, -1000, 1000, 0, grey)]
+
+    def trs(t, angle, axis, scale):
+        a = np.radians(angle)
+        c, si = np.cos(a), np.sin(a)
+        x, y, z = np.asarray(axis) / np.linalg.norm(axis)
+        r = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * si, x * z * (1 - c) + y * si, 0],
+                      [y * x * (1 - c) + z * si, c + y * y * (1 - c), y * z * (1 - c) - x * si, 0],
+                      [z * x * (1 - c) - y * si, z * y * (1 - c) + x * si, c + z * z * (1 - c), 0], [0, 0, 0, 1]])
+        m = np.eye(4); m[:3, 3] = t
+        return (m @ r @ np.diag(list(scale) + [1.0])).astype(np.float32)
+
+    for i in range(60):
+        pos = (float(rng.uniform(-8, 8)), float(rng.uniform(0.8, 3.0)), float(rng.uniform(-8, 8)))
+        m = trs(pos, float(rng.uniform(0, 360)), rng.normal(size=3), rng.uniform(0.5, 1.6, 3).tolist())
+        mtl = [s.lambertian(s.solid(*rng.uniform(0.2, 0.9, 3).tolist())), s.metal(0.8, 0.8, 0.7, 0.05), s.dielectric(1.5)][i % 3]
+        inner = s.sphere((0, 0, 0), 0.5, mtl) if i % 5 == 4 else s.block((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), mtl)
+        objs.append(s.transform(inner, m))
+    objs.append(s.flip_face(s.xz_rect(-4, 4, -4, 4, 9, s.diffuse_light(s.solid(5, 5, 5)))))
+    s.set_roots(s.hittable_list(objs), s.hittable_list([s.xz_rect(-4, 4, -4, 4, 9, s.diffuse_light(s.solid(0, 0, 0)))]))
+    flat = s.flatten()
+    assert flat.desc.always_count == 0 and flat.desc.n_slots == 1 + 48 * 6 + 12 + 1 and flat.desc.n_matrices == 60
+    params = rt.host.RaytracerConfig.load().scene_params("CornellBox").replace(
+        image_width=128, aspect_ratio=1.6, samples_per_pixel=16, look_from=(0.0, 6.0, 16.0), look_at=(0.0, 1.5, 0.0),
+        vertical_fov=40.0, background=(0.3, 0.4, 0.6))
+    camera = params.camera()
+    sampler = rt.host.MultiJitteredSampler(16)
+    gpu.upload_scene(flat)
+    gpu.upload_sampler(sampler)
+    oracle = O.OracleScene(s)
+    rays = primary_and_bounce_rays(rt, s, params, camera, 1 << 15)
+    g, exact = check_first_hit(gpu, oracle, rays)
+    assert exact
+    hit = g[0] != 0xFFFFFFFF
+    check_first_hit(gpu, oracle, bounce_rays(rays, g[1], g[2], hit))
+    img, _, st = compare_images(rt, gpu, oracle, params, camera, sampler)
+    assert st["node_visits"] > 0
+    # and on a tree built on the device
+    gpu.upload_scene(s.flatten(device_bvh=True))
+    img2, _ = gpu.render(params, camera)
+    assert np.array_equal(img2.view(np.uint32), img.view(np.uint32))

@@ -245,8 +245,9 @@ def test_flatten_bvh_invariants(rt):
     assert ((w4 & 16) != 0).sum() == 1                            # one FlipFace'd light
 
 
-def test_quadrics_and_transformed_slots_stay_out_of_the_bvh(rt):
-    # cone / paraboloid / hyperboloid accept hits below t_min (cone.rs:61-65): they are tested for every ray
+def test_quadrics_stay_out_of_the_bvh(rt):
+    # cone / paraboloid / hyperboloid accept hits below t_min (cone.rs:61-65): they are tested for every ray;
+    # slots under a general Transform honour t_min and go through the BVH like any other
     s = rt.host.Scene()
     m = s.lambertian(s.solid(1, 1, 1))
     objs = [s.sphere((3.0 * i, 0, 0), 1, m) for i in range(40)]
@@ -256,13 +257,15 @@ def test_quadrics_and_transformed_slots_stay_out_of_the_bvh(rt):
     s.set_roots(s.hittable_list(objs), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
     f = s.flatten()
     d = f.desc
-    assert d.n_slots == 43 and d.always_begin == 40 and d.always_count == 3 and d.n_bvh_nodes > 0
+    assert d.n_slots == 43 and d.always_begin == 41 and d.always_count == 2 and d.n_bvh_nodes > 0
     check_bvh(f)
     sl = f.slots()
-    assert (sl[40:, 4].view(np.int32) & 15).tolist() == [7, 9, 0]
-    assert sl[40:, 6].view(np.int32).tolist() == [40, 41, 42]      # primitive ids follow the world list
-    assert (sl[42, 4].view(np.int32) & 16) != 0                    # FlipFace inside a Transform survives (transform.rs:198-202)
-    assert np.allclose(sl[41, 12:14], [1.0, 0.0])                  # x^2 + y^2 - 0 z^2 = 1: ah = 1, ch = 0
+    assert (sl[41:, 4].view(np.int32) & 15).tolist() == [7, 9]
+    assert sl[41:, 6].view(np.int32).tolist() == [40, 41]          # primitive ids follow the world list
+    ball = sl[sl[:, 6].view(np.int32) == 42][0]                    # the transformed sphere sits in a BVH leaf
+    assert (ball[4:5].view(np.int32)[0] & 16) != 0                 # FlipFace inside a Transform survives (transform.rs:198-202)
+    assert (ball[4:5].view(np.int32)[0] >> 8) > 0
+    assert np.allclose(sl[42, 12:14], [1.0, 0.0])                  # x^2 + y^2 - 0 z^2 = 1: ah = 1, ch = 0
 
 
 def test_unsupported_nesting_is_reported(rt):
