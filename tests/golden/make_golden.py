@@ -192,6 +192,154 @@ def image_texel(w, h, u, v):
     return min(i, w - 1), min(j, h - 1)
 
 
+def mat4_inverse_and_normal(m):
+    """math/src/mat4.rs:536-617 (det with its two index typos, adjoint, invert) and transform.rs:171
+    (normal2world = adjoint(world2object) transposed).  m: 4x4 list of f32, row-major."""
+    def det(m):
+        k1 = m[0][0] * m[1][1] - m[0][1] * m[1][0]; l1 = m[2][2] * m[3][3] - m[2][3] * m[3][2]
+        k2 = m[0][0] * m[1][2] - m[0][2] * m[1][0]; l2 = m[2][1] * m[3][3] - m[1][2] * m[3][1]
+        k3 = m[0][0] * m[1][3] - m[0][3] * m[1][0]; l3 = m[2][1] * m[3][2] - m[2][2] * m[3][1]
+        k4 = m[0][1] * m[1][2] - m[0][2] * m[1][1]; l4 = m[2][0] * m[3][3] - m[3][2] * m[3][0]
+        k5 = m[0][1] * m[1][3] - m[0][3] * m[1][1]; l5 = m[2][0] * m[3][2] - m[2][2] * m[3][0]
+        k6 = m[0][2] * m[1][3] - m[0][3] * m[1][2]; l6 = m[2][0] * m[3][1] - m[2][1] * m[3][0]
+        return k1 * l1 - k2 * l2 + k3 * l3 + k4 * l4 - k5 * l5 + k6 * l6
+
+    def adjoint(m):
+        m1 = m[2][2] * m[3][3] - m[2][3] * m[3][2]; m2 = m[2][1] * m[3][3] - m[2][3] * m[3][1]
+        m3 = m[2][1] * m[3][2] - m[2][2] * m[3][1]; m4 = m[0][2] * m[1][3] - m[0][3] * m[1][2]
+        m5 = m[0][1] * m[1][3] - m[0][3] * m[1][1]; m6 = m[0][1] * m[1][2] - m[0][2] * m[1][1]
+        m7 = m[2][0] * m[3][3] - m[2][3] * m[3][0]; m8 = m[2][0] * m[3][2] - m[2][2] * m[3][0]
+        m9 = m[1][2] * m[3][3] - m[1][3] * m[3][2]; m10 = m[1][0] * m[3][3] - m[1][3] * m[3][0]
+        m11 = m[1][0] * m[3][2] - m[1][2] * m[3][0]; m12 = m[0][0] * m[1][3] - m[0][3] * m[1][0]
+        m13 = m[0][0] * m[1][2] - m[0][2] * m[1][0]; m14 = m[2][0] * m[3][1] - m[2][1] * m[3][0]
+        m15 = m[0][0] * m[1][1] - m[0][1] * m[1][0]; m16 = m[2][0] * m[3][1] - m[2][1] * m[3][0]
+        return [[m[1][1] * m1 - m[1][2] * m2 + m[1][3] * m3, -m[0][1] * m1 + m[0][2] * m2 - m[0][3] * m3,
+                 m[3][1] * m4 - m[3][2] * m5 + m[3][3] * m6, -m[2][1] * m4 + m[2][2] * m5 - m[2][3] * m6],
+                [-m[1][0] * m1 + m[1][2] * m7 - m[1][3] * m8, m[0][0] * m1 - m[0][2] * m7 + m[0][3] * m8,
+                 -m[0][0] * m9 + m[0][2] * m10 - m[0][3] * m11, m[2][0] * m4 - m[2][2] * m12 + m[2][3] * m13],
+                [m[1][0] * m2 - m[1][1] * m7 + m[1][3] * m16, -m[0][0] * m2 + m[0][1] * m7 - m[0][3] * m16,
+                 m[3][0] * m5 - m[3][1] * m12 + m[3][3] * m15, -m[2][0] * m5 + m[2][1] * m12 - m[2][3] * m15],
+                [-m[1][0] * m3 + m[1][1] * m8 - m[1][2] * m14, m[0][0] * m3 - m[0][1] * m8 + m[0][2] * m14,
+                 -m[3][0] * m6 + m[3][1] * m13 - m[3][2] * m15, m[2][0] * m6 - m[2][1] * m13 + m[2][2] * m15]]
+    d = det(m)
+    inv = F(1) / d
+    w2o = [[e * inv for e in row] for row in adjoint(m)]
+    adj = adjoint(w2o)
+    n2w = [[adj[c][r] for c in range(4)] for r in range(4)]
+    return w2o, n2w
+
+
+def mat_vec(m, v, w):
+    """math/src/mat4.rs:434-441 followed by .xyz()"""
+    w = F(w)
+    return [m[r][0] * v[0] + m[r][1] * v[1] + m[r][2] * v[2] + m[r][3] * w for r in range(3)]
+
+
+def poly_quadratic(a, b, c):
+    """math/src/polynomial.rs:11-39 -> (count, [r0, r1]) with the caller's zero-initialised roots"""
+    zero = F(0)
+    if a == 0:
+        if b == 0:
+            return 0, [zero, zero]
+        return 1, [-c / b, zero]
+    delta = b * b - F(4) * a * c
+    if delta == 0:
+        r = -b / F(2) * a
+        return 2, [r, r]
+    if not delta < 0:
+        sgn = np.copysign(F(1), b)
+        q = -(b + sgn * np.sqrt(delta)) / F(2)
+        r0, r1 = q / a, c / q
+        if r0 > r1:
+            r0, r1 = r1, r0
+        return 2, [r0, r1]
+    return 0, [zero, zero]
+
+
+def quadric_hit(kind, prm, m, o, d, t_min, t_max):
+    """cylinder.rs:52-128, cone.rs:35-121, paraboloid.rs:48-144 under an optional Transform (transform.rs:184-204).
+    phi only decides the clipping here (its bits depend on the atan2 in use), so cases keep phi_max = 2 pi or stay clear of it."""
+    o, d, t_min, t_max = vec(o), vec(d), F(t_min), F(t_max)
+    prm = [F(x) for x in prm]
+    o_w, d_w = o, d
+    if m is not None:
+        m = [[F(x) for x in row] for row in m]
+        w2o, n2w = mat4_inverse_and_normal(m)
+        o, d = mat_vec(w2o, o, 1), mat_vec(w2o, d, 0)
+    two, two_pi = F(2), F(np.pi) * F(2)
+    with np.errstate(all="ignore"):
+        if kind == "cylinder":
+            radius, zmin, zmax, phi_max = prm
+            a = d[0] * d[0] + d[1] * d[1]
+            b = two * (d[0] * o[0] + d[1] * o[1])
+            c = o[0] * o[0] + o[1] * o[1] - radius * radius
+        elif kind == "cone":
+            radius, height, phi_max = prm
+            zmin, zmax = F(0), height
+            k = radius / height
+            k = k * k
+            a = d[0] * d[0] + d[1] * d[1] - k * d[2] * d[2]
+            b = two * (d[0] * o[0] + d[1] * o[1] - k * d[2] * (o[2] - height))
+            c = o[0] * o[0] + o[1] * o[1] - k * (o[2] - height) * (o[2] - height)
+        else:
+            radius, zmin, zmax, phi_max = prm
+            k = zmax / (radius * radius)
+            a = k * (d[0] * d[0] + d[1] * d[1])
+            b = two * k * (d[0] * o[0] + d[1] * o[1]) - d[2]
+            c = k * (o[0] * o[0] + o[1] * o[1]) - o[2]
+        n, (t0, t1) = poly_quadratic(a, b, c)
+        if n == 0:
+            return None
+        if kind == "cylinder":
+            if t0 > t_max or t1 < t_min:
+                return None
+            thit = t1 if t0 < t_min else t0
+        else:
+            if t0 > t_max or t1 <= 0:
+                return None
+            thit = t1 if t0 <= 0 else t0
+        if thit > t_max:
+            return None
+
+        def phi_of(p):
+            phi = F(np.arctan2(p[1], p[0]))
+            return phi + two_pi if phi < 0 else phi
+        p = at(o, d, thit)
+        phi = phi_of(p)
+        if p[2] < zmin or p[2] > zmax or phi > phi_max:
+            if thit == t1:
+                return None
+            thit = t1
+            if t1 > t_max:
+                return None
+            p = at(o, d, thit)
+            phi = phi_of(p)
+            if p[2] < zmin or p[2] > zmax or phi > phi_max:
+                return None
+        zero = F(0)
+        if kind == "cylinder":
+            v = (p[2] - zmin) / (zmax - zmin)
+            dpdu, dpdv = [-phi_max * p[1], phi_max * p[0], zero], [zero, zero, zmax - zmin]
+            n_out = normalize(cross(dpdv, dpdu))
+        elif kind == "cone":
+            v = p[2] / height
+            dpdu = [-phi_max * p[1], phi_max * p[1], zero]
+            dpdv = [-p[0] / (F(1) - v), -p[1] / (F(1) - v), height]
+            n_out = normalize(cross(dpdu, dpdv))
+        else:
+            v = (p[2] - zmin) / (zmax - zmin)
+            dpdu = [-phi_max * p[1], phi_max * p[0], zero]
+            s = zmax - zmin
+            dpdv = [s * (p[0] / (two * p[2])), s * (p[1] / (two * p[2])), s * F(1)]
+            n_out = normalize(cross(dpdu, dpdv))
+        front = dot(d, n_out) < 0
+        nn = n_out if front else [-x for x in n_out]
+        if m is not None:
+            p = mat_vec(m, p, 1)
+            nn = normalize(mat_vec(n2w, nn, 0))
+    return {"t": bits(thit), "p": vbits(p), "normal": vbits(nn), "front_face": int(front), "v": bits(v)}
+
+
 def main():
     out = {}
     sph = []
@@ -258,6 +406,40 @@ def main():
     # the reference's own adjacent known answer: math/src/mat4.rs:641-655
     out["mat4_mul"] = {"a": list(range(1, 17)), "b": list(range(17, 33)),
                        "result": [250, 260, 270, 280, 618, 644, 670, 696, 986, 1028, 1070, 1112, 1354, 1412, 1470, 1528]}
+    # quadrics, alone and under general Transforms (rotation about a tilted axis, non-uniform scale, translation)
+    def trs(t, angle_deg, axis, scale):
+        ax = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+        c, si = np.cos(np.radians(angle_deg)), np.sin(np.radians(angle_deg))
+        x, y, z = ax
+        r = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * si, x * z * (1 - c) + y * si, 0],
+                      [y * x * (1 - c) + z * si, c + y * y * (1 - c), y * z * (1 - c) - x * si, 0],
+                      [z * x * (1 - c) - y * si, z * y * (1 - c) + x * si, c + z * z * (1 - c), 0], [0, 0, 0, 1]])
+        tm = np.eye(4); tm[:3, 3] = t
+        return [[float(F(e)) for e in row] for row in (tm @ r @ np.diag(list(scale) + [1.0]))]
+    two_pi = float(F(np.pi) * F(2))
+    shapes = [("cylinder", [1.0, -0.5, 0.5, two_pi]), ("cone", [1.0, 1.0, two_pi]), ("paraboloid", [0.5, -0.5, 1.0, two_pi]),
+              ("cylinder", [0.7, -1.0, 2.0, two_pi]), ("cone", [0.5, 2.0, two_pi]), ("paraboloid", [1.0, 0.0, 1.0, two_pi])]
+    mats = [None, trs((3, 1, -2), 37, (1, 2, 3), (1.5, 0.5, 2.0)), trs((-1, 0.5, 4), -110, (0, 1, 0.3), (2, 2, 2)), trs((0, 0, 0), 63, (1, 0, 0), (1, 1, 1))]
+    rng = np.random.default_rng(12345)
+    quads = []
+    for si, (kind, prm) in enumerate(shapes):
+        for mi, m in enumerate(mats):
+            kept = 0
+            while kept < 3:
+                # aim at a point near the shape from a point a few units away (world space)
+                centre = np.array([0.0, 0.0, 0.3]) if m is None else (np.asarray(m, np.float64) @ np.array([0, 0, 0.3, 1.0]))[:3]
+                o = centre + rng.normal(size=3) * 4.0
+                target = centre + rng.normal(size=3) * (0.5 if m is None else 1.0)
+                dd = target - o
+                o_, d_ = [float(F(x)) for x in o], [float(F(x)) for x in dd]
+                t_min, t_max = (0.001, float("inf")) if kept != 2 else (0.001, 1.5)
+                h = quadric_hit(kind, prm, m, o_, d_, t_min, t_max)
+                if h is None and kept == 0:
+                    continue                                   # the first case of every pair is a hit
+                quads.append({"kind": kind, "params": prm, "matrix": m, "o": o_, "d": d_, "t_min": t_min,
+                              "t_max": "inf" if t_max == float("inf") else t_max, "hit": h})
+                kept += 1
+    out["quadric"] = quads
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -62,6 +62,14 @@ def test_golden_vectors_through_the_c_abi(rt, gpu):
         run(lambda s, m: [getattr(s, mk)(c["a0"], c["a1"], c["b0"], c["b1"], c["k"], m)], c)
 
 
+def test_quadric_golden_vectors_through_the_c_abi(rt, gpu):
+    """tests/golden/kat.json quadric + Transform vectors via rt_trace_first_hit: bit-exact."""
+    from test_oracle_kat import check_quadric, quadric_scene
+    for case in KAT["quadric"]:
+        gpu.upload_scene(quadric_scene(case).flatten())
+        check_quadric(gpu.trace_first_hit, case)
+
+
 def test_c1_book1_full_frame(rt, gpu):
     scene, params, camera, sampler = setup(rt, gpu, "C1")
     assert (params.image_width, params.image_height, sampler.spp) == (1200, 675, 10)

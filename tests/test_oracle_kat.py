@@ -345,3 +345,31 @@ def test_transform_known_answers():
         fl = scene_with(lambda s, m: [wrap(s, s.block((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), m))])
         pid, t, n, ff, uv = one_hit(fl, (20, 0.3, 0.2), (-1, 0, 0))
         assert (pid, t, ff) == (4, 9.0, False) and np.allclose(n, [1, 0, 0])
+
+
+def quadric_scene(case):
+    """One quadric (and its Transform) as the only object of a scene: primitive id 0."""
+    def build(s, m):
+        kind, prm = case["kind"], case["params"]
+        q = {"cylinder": lambda: s.cylinder(prm[0], prm[1], prm[2], prm[3], m), "cone": lambda: s.cone(prm[0], prm[1], prm[2], m),
+             "paraboloid": lambda: s.paraboloid(prm[0], prm[1], prm[2], prm[3], m)}[kind]()
+        return [q if case["matrix"] is None else s.transform(q, np.array(case["matrix"], np.float32))]
+    return scene_with(build)
+
+
+def check_quadric(first_hit, case):
+    pid, t, n, ff, uv = first_hit(ray(case["o"], case["d"]), case["t_min"], tmax(case))
+    want = case["hit"]
+    if want is None:
+        assert pid[0] == 0xFFFFFFFF, case
+        return
+    assert pid[0] == 0 and int(t.view(np.uint32)[0]) == want["t"], case
+    assert list(n.view(np.uint32)[0]) == want["normal"] and ff[0] == want["front_face"], case
+    assert int(uv.view(np.uint32)[0, 1]) == want["v"], case          # u = phi / phi_max depends on the atan2 in use: not pinned here
+
+
+@pytest.mark.parametrize("case", KAT["quadric"], ids=lambda c: "%s%s" % (c["kind"], "" if c["matrix"] is None else "-xf"))
+def test_quadrics_and_transform_against_the_numpy_restatement(case):
+    """tests/golden/make_golden.py restates cylinder.rs / cone.rs / paraboloid.rs / polynomial.rs / transform.rs / mat4.rs
+    independently (numpy f32, one operation at a time): t, normal, front_face and v must agree bit for bit."""
+    check_quadric(O.OracleScene(quadric_scene(case)).first_hit, case)
