@@ -19,6 +19,7 @@
 #ifndef RT_HOST_H
 #define RT_HOST_H
 
+#include <stddef.h>
 #include <stdint.h>
 #include "rt_api.h"
 #include "rt_scene_graph.h"
@@ -164,6 +165,16 @@ int rth_checkpoint_save(const char *path, int32_t width, int32_t height, int32_t
                         const float *rgba_sum);
 int rth_checkpoint_load(const char *path, int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed, float *rgba_sum,
                         int32_t *spp_done);
+
+/* ------------------------------------------------------------------ input
+ * ImageTexture::new (image_texture.rs:20-38): `image::io::Reader::open(p).decode().into_rgba8()` — a texture file to
+ * width * height * 4 bytes RGBA, row 0 = top, for rth_add_image_texture / rth_scene_assets.  Baseline JPEG (grey or
+ * YCbCr, any chroma sampling, restart intervals) and non-interlaced 8/16-bit PNG; anything else -> RT_E_UNSUPPORTED_PRIMITIVE.
+ * The JPEG arithmetic restates jpeg-decoder 0.3.0 (Cargo.lock; not under /root/reference): parity unpinned, see
+ * csrc/rt_host_image.cpp.  *rgba is malloc'ed by the library: release it with rth_image_free. */
+int  rth_image_decode(const uint8_t *data, size_t size, int32_t *width, int32_t *height, uint8_t **rgba);
+int  rth_image_decode_file(const char *path, int32_t *width, int32_t *height, uint8_t **rgba);
+void rth_image_free(uint8_t *rgba);
 
 /* WorkBlock list of main.rs:1265-1282 (no shuffle): writes up to cap entries of x0,x1,y0,y1
  * and returns the number of blocks. */

@@ -173,7 +173,7 @@ HOST_SYMBOLS = [
     "rth_sampler_new", "rth_sampler_free", "rth_sampler_desc", "rth_flatten", "rth_flat_free", "rth_flat_desc",
     "rth_work_blocks", "rth_mat4_mul", "rth_mat4_invert", "rth_add_transform", "rth_add_cylinder", "rth_add_cone",
     "rth_add_paraboloid", "rth_add_hyperboloid", "rth_flatten_opts", "rth_write_png_rgb8", "rth_checkpoint_save",
-    "rth_checkpoint_load",
+    "rth_checkpoint_load", "rth_image_decode", "rth_image_decode_file", "rth_image_free",
 ]
 
 HIP_SYMBOLS = [
@@ -252,6 +252,9 @@ def host_lib():
     L.rth_write_png_rgb8.argtypes = [C.c_char_p, i32, i32, c_u8_p]
     L.rth_checkpoint_save.argtypes = [C.c_char_p, i32, i32, i32, i32, u32, c_float_p]
     L.rth_checkpoint_load.argtypes = [C.c_char_p, i32, i32, i32, u32, c_float_p, C.POINTER(i32)]
+    L.rth_image_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(i32), C.POINTER(i32), C.POINTER(c_u8_p)]
+    L.rth_image_decode_file.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(c_u8_p)]
+    L.rth_image_free.argtypes = [c_u8_p]; L.rth_image_free.restype = None
     L.rth_work_blocks.argtypes = [i32, i32, i32, C.POINTER(i32), i32]
     L.rth_mat4_mul.argtypes = [C.c_float * 16, C.c_float * 16, C.c_float * 16]; L.rth_mat4_mul.restype = None
     L.rth_mat4_invert.argtypes = [C.c_float * 16, C.c_float * 16]

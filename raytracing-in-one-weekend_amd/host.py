@@ -146,12 +146,26 @@ class Geometry:
             self._h = None
 
 
+def _take_image(status, w, h, px):
+    _check(status)
+    try:
+        return np.ctypeslib.as_array(px, (h.value, w.value, 4)).copy()
+    finally:
+        _ffi.host_lib().rth_image_free(px)
+
+
 def load_image_rgba(path):
-    """ImageTexture::new (image_texture.rs:20-38): decode + into_rgba8.  The reference uses the
-    `image` crate's JPEG decoder; here PIL decodes (IDCT rounding can differ by 1 LSB)."""
-    from PIL import Image
-    im = Image.open(path).convert("RGBA")
-    return np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+    """ImageTexture::new (image_texture.rs:20-38): decode + into_rgba8, H x W x 4 uint8.  The host library's own
+    decoder (csrc/rt_host_image.cpp: baseline JPEG restating jpeg-decoder 0.3.0, PNG); no PIL on the asset path."""
+    w, h, px = C.c_int32(), C.c_int32(), _ffi.c_u8_p()
+    return _take_image(_ffi.host_lib().rth_image_decode_file(os.fspath(path).encode(), C.byref(w), C.byref(h), C.byref(px)), w, h, px)
+
+
+def decode_image_rgba(data):
+    """The same for a file already in memory (e.g. an image embedded in a GLB, geometry_import.rs:461-488)."""
+    w, h, px = C.c_int32(), C.c_int32(), _ffi.c_u8_p()
+    data = bytes(data)
+    return _take_image(_ffi.host_lib().rth_image_decode(data, len(data), C.byref(w), C.byref(h), C.byref(px)), w, h, px)
 
 
 class Assets:
