@@ -195,6 +195,16 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     }
     unsigned long long *d_stats = (STATS || kTimers) ? ctx->d_stats : nullptr;
     if (STATS || kTimers) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 64 * sizeof(unsigned long long), stream));
+    // the tail kernel (rt_wavefront.h): finishes the last RT_WF_TAIL paths of a batch in one launch; 0 = never.  Default: on for
+    // scenes without a BVH walk (measured on MI355X, 32768 against 0: C2 at 16 / 64 / 1000 spp +18 / +8 / +1 %), off with one:
+    // there a bounce costs a lone wave as much as an iteration costs the pipeline (C4 at 4 spp +22 %, but C1 at 10 spp, whose last
+    // paths rattle inside glass spheres for 40 bounces, -23 %).
+    auto *const tail_kernel = ctx->bvh_has_general_xform ? wf_tail_kernel<STATS, EXT_XFORM> : wf_tail_kernel<STATS, EXT_NONE>;
+    const uint32_t tail_max = (uint32_t)env_size("RT_WF_TAIL", has_bvh ? 0 : 32768, 0, 1u << 20);
+    unsigned tail_nb = (tail_max + 4095u) / 4096u;                       // one lane per path: 64 shards x tail_nb waves
+    if (tail_nb > trav_blocks / 16u) tail_nb = trav_blocks / 16u;        // its lanes share the pipeline's stack overflow area
+    if (tail_nb < 1u) tail_nb = 1u;
+    const size_t tail_lds = (size_t)lds_depth * 64 * sizeof(StackEntry);
 
     struct Pipe {
         hipStream_t s;
@@ -266,6 +276,9 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                                        ctx->wf_samples, d_stats, d_rays);
                     hipLaunchKernelGGL(wf_generate_kernel<STATS>, dim3(P.pool_blocks), dim3(256), 0, P.s, ctx->sc, P.w, nxt, P.ctr, it,
                                        ctx->wf_samples, P.d_status, d_stats, d_rays);
+                    if (tail_max && (k & 3) == 3)
+                        hipLaunchKernelGGL(tail_kernel, dim3(RT_WF_SHARDS * tail_nb), dim3(64), tail_lds, P.s, ctx->sc, P.w, nxt, P.ctr, it + 1u,
+                                           tail_max, lds_depth, P.ovf, ctx->wf_samples, P.d_status, d_stats, d_rays);
                 }
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipMemcpyAsync(P.h_status + 4 * (group & 1), P.d_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, P.s));

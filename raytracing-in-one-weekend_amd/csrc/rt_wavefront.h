@@ -429,6 +429,106 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
     if (STATS || kTimers) flush_counters<STATS>(cnt, 0u, stats);
 }
 
+/* ------------------------------------------------------------------ tail */
+
+// The last paths of a batch.  Once every item has been handed out the pool only shrinks, and a few long paths keep it
+// alive for dozens of iterations that each cost three launches' worth of fixed time.  This kernel is launched between
+// iterations; it does nothing (one counter read per wave) until all items are out and at most tail_max paths live, then
+// runs each of them to its end in one lane — the walk, the shade and begin_trace of every remaining bounce, the same
+// functions in the same order, hence the same bits — parks the samples and marks the entries dead, so the next
+// iteration finds an empty pool.  One wave per block: a block's waves would only wait for each other.
+template <bool STATS, int EXT>
+__global__ void __launch_bounds__(64) wf_tail_kernel(DScene sc, WfArgs w, PathQ q, const WfCounters *ctr, uint32_t it, uint32_t tail_max,
+                                                     uint32_t lds_depth, StackEntry *ovf, float4 *__restrict__ samples, uint32_t *status,
+                                                     unsigned long long *stats, uint32_t *pixel_rays) {
+    extern __shared__ StackEntry lds_stack[];
+    const uint32_t lane = threadIdx.x;
+    const WfCounters *c = ctr + (it % RT_WF_RING);      // written by the generate before this launch, by nobody during it
+    uint32_t live = wave_sum(c->sh[lane].count_in);
+    live = (uint32_t)__shfl((int)live, 0, 64);
+    if (live == 0u || live > tail_max || c->sh[0].item_head != w.n_items) return;      // the same answer in every block
+    if (blockIdx.x == 0 && lane == 0) status[0] = 0u;   // what the next generate would report
+    const uint32_t shard = blockIdx.x % RT_WF_SHARDS, b = blockIdx.x / RT_WF_SHARDS, nb = gridDim.x / RT_WF_SHARDS;
+    const uint32_t n = c->sh[shard].count_in;
+    const Stack stack{lds_stack + lane, blockDim.x, lds_depth, ovf ? ovf + (size_t)blockIdx.x * blockDim.x + lane : nullptr, gridDim.x * blockDim.x};
+    const V3 background = v3(w.a.bg[0], w.a.bg[1], w.a.bg[2]);
+    const float T_MIN = 0.001f;
+    Counters cnt{};
+    for (uint32_t off = b * 64u; off < n; off += nb * 64u) {
+        const uint32_t i = shard * w.cap + off + lane;
+        bool alive = false, walk = false;
+        WfPath p;
+        p.ps.ray.o = v3(0.0f, 0.0f, 0.0f); p.ps.ray.d = p.ps.ray.o; p.ps.ray.time = 0.0f;
+        p.ps.throughput = p.ps.ray.o; p.ps.radiance = p.ps.ray.o; p.ps.depth = 0;
+        p.pixel = 0; p.sample = 0; p.item = 0; p.rng.state = 0; p.rng.inc = 1;
+        Trav tv;
+        tv.ref = RT_BVH_EMPTY; tv.sp = 0; tv.best.t = 0.0f; tv.best.id = -1; tv.best.slot = 0; tv.floor_id = -1;
+        tv.inv = p.ps.ray.o; tv.oi = p.ps.ray.o;
+        if (off + lane < n) {
+            const float4 d = q.ray_d[i];
+            const uint32_t flags = __float_as_uint(d.w);
+            if (flags & WF_ALIVE) {
+                const float4 o = q.ray_o[i], th = q.thr[i], h = q.hit[i];
+                const float2 rg = q.rng[i];
+                alive = true;
+                walk = (flags & WF_WALK) != 0u;
+                p.ps.ray.o = v3(o.x, o.y, o.z); p.ps.ray.d = v3(d.x, d.y, d.z); p.ps.ray.time = o.w;
+                p.ps.throughput = v3(th.x, th.y, th.z); p.item = __float_as_uint(th.w);
+                p.ps.depth = (int)(flags & WF_DEPTH_MASK);
+                int px, py;
+                item_pixel(w, p.item, &px, &py, &p.sample);
+                p.pixel = (uint32_t)py * (uint32_t)w.a.width + (uint32_t)px;
+                p.rng.state = ((uint64_t)__float_as_uint(rg.y) << 32) | (uint64_t)__float_as_uint(rg.x);
+                p.rng.inc = (((((uint64_t)p.pixel << 24) ^ (uint64_t)p.sample)) << 1u) | 1u;   // rts::path_rng's stream
+                tv.best.t = h.x; tv.best.id = f2i(h.y); tv.best.slot = f2i(h.z); tv.floor_id = f2i(h.w);
+                if (walk) {     // as the traverse kernel starts a walk: the box-test arithmetic of begin_trace()
+                    const Ray &r = p.ps.ray;
+                    float dx = fabsf(r.d.x) < 1.0e-30f ? 1.0e-30f : r.d.x;
+                    float dy = fabsf(r.d.y) < 1.0e-30f ? 1.0e-30f : r.d.y;
+                    float dz = fabsf(r.d.z) < 1.0e-30f ? 1.0e-30f : r.d.z;
+                    tv.inv = v3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+                    tv.oi = r.o * tv.inv;
+                    tv.sp = 0;
+                    tv.ref = sc.root_ref;
+                }
+                q.ray_d[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));      // dead: traverse and shade skip it
+            }
+        }
+        while (__ballot(alive) != 0ull) {
+            for (;;) {      // the walk, "while-while" as in the traverse kernel
+                const bool on_node = alive && walk && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY;
+                phase_count<STATS>(cnt, PH_NODE, on_node);
+                if (on_node) trav_node_step<STATS>(sc, T_MIN, tv, stack, cnt);
+                const bool at_leaf = alive && walk && tv.ref < 0;
+                const unsigned long long m_leaf = __ballot(at_leaf);
+                const unsigned long long m_node = __ballot(alive && walk && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
+                if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
+                    phase_count<STATS>(cnt, PH_LEAF, at_leaf);
+                    if (at_leaf) trav_leaf_step<STATS, EXT>(sc, p.ps.ray, T_MIN, tv, stack, cnt);
+                } else if (m_node == 0ull) {
+                    break;
+                }
+            }
+            phase_count<STATS>(cnt, PH_SHADE, alive);
+            bool survive = false;
+            if (alive) {
+                finish_trace<STATS>(sc, p.ps.ray, T_MIN, INFINITY, tv, cnt);
+                survive = shade_hit<STATS>(sc, p.ps, tv.best, background, p.rng, cnt) && p.ps.depth > 0;
+                if (!survive) {
+                    samples[p.item] = make_float4(p.ps.radiance.x, p.ps.radiance.y, p.ps.radiance.z, 0.0f);
+                    alive = false;
+                }
+            }
+            phase_count<STATS>(cnt, PH_BEGIN, survive);
+            if (survive) {
+                if (STATS) { cnt.rays += 1; if (pixel_rays) atomicAdd(&pixel_rays[p.pixel], 1u); }
+                walk = begin_trace<STATS>(sc, p.ps.ray, T_MIN, INFINITY, p.rng, tv, cnt);
+            }
+        }
+    }
+    if (STATS || kTimers) flush_counters<STATS>(cnt, 0u, stats);
+}
+
 /* ------------------------------------------------------------------ fold */
 
 // pixel_color += ray_color(sample k), k ascending (camera.rs:195-250): one thread per pixel of the window.

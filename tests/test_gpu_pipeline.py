@@ -59,6 +59,9 @@ def test_reference_image_matches_the_oracle(rt, gpu, book2):
     {"RT_WF_POOL_LOG2": 15, "RT_WF_PIPES": 1},
     {"RT_WF_LDS_DEPTH": 3},                        # almost the whole traversal stack in the HBM overflow area
     {"RT_WF_SAMPLES_MB": 1},                       # 64 Ki samples per batch -> several batches, several folds
+    {"RT_WF_TAIL": 32768},                         # the last paths finished by wf_tail_kernel (off by default with a BVH)
+    {"RT_WF_TAIL": 1000000},                       # ... everything that is left once all items are out
+    {"RT_WF_TAIL": 3000, "RT_WF_LDS_DEPTH": 3, "RT_WF_PIPES": 1},   # ... with its stack in the overflow area
 ])
 def test_image_is_independent_of_the_pipeline_geometry(gpu, book2, env):
     scene, params, camera, sampler, ref = book2
@@ -89,6 +92,28 @@ def test_counting_variant_traces_the_same_paths(gpu, book2):
     assert sum(st["shades"]) == st["accepted_hits"]
     # every node visit and leaf visit is a lane doing a phase
     assert st["phase_lanes"][0] == st["node_visits"]
+
+
+def test_tail_kernel_changes_no_bit(rt, gpu, book2):
+    # scenes without a BVH walk (Cornell: 13 leaves, flat scan) finish their last paths in wf_tail_kernel by default
+    scene, params, camera, sampler = rt.configs.build("C2", image_width=64, samples_per_pixel=36)
+    gpu.upload_scene(scene.flatten())
+    gpu.upload_sampler(sampler)
+    try:
+        with knobs(RT_WF_TAIL=0):
+            ref, st0, rays0 = gpu.render(params, camera, stats=True, want_pixel_rays=True)
+        got, st1, rays1 = gpu.render(params, camera, stats=True, want_pixel_rays=True)
+        assert same_bits(got, ref) and np.array_equal(rays0, rays1)
+        for k in ("paths", "rays", "prim_tests", "shades", "tex_evals", "light_pdf_evals", "accepted_hits"):
+            assert st0[k] == st1[k], k
+        plain, _ = gpu.render(params, camera)
+        assert same_bits(plain, ref)
+        with knobs(RT_WF_TAIL=64):
+            assert same_bits(gpu.render(params, camera)[0], ref)
+    finally:
+        s3, p3, c3, sm3, _ = book2
+        gpu.upload_scene(s3.flatten())
+        gpu.upload_sampler(sm3)
 
 
 def test_depth_zero_and_empty_ranges(rt, gpu, book2):
