@@ -6,7 +6,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); meta = {}
 for part in "abcd":
     for f in glob.glob("gpurun_out/pmc_%s_%s/*/*counter_collection.csv" % (tag, part)):
         for r in csv.DictReader(open(f)):
-            m = re.search(r"rtk::(\w+)<false>|rtk::(wf_fold_kernel)", r["Kernel_Name"])
+            m = re.search(r"rtk::(\w+)<false[,>]|rtk::(wf_fold_kernel)", r["Kernel_Name"])
             if not m: continue
             k = m.group(1) or m.group(2)
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
