@@ -6,6 +6,8 @@ image size / spp of BASELINE.json on top:
   C2  CornellBox      600x600 1000 spp   default_params camera, aspect 1.0
   C3  Chapter2Final   800x800  10k spp   config camera
   C4  MeshTest       1920x1080 256 spp   config camera, K x K teapots (K=10 -> 2.26 M triangles)
+  C5  Chapter2Final  3840x2160 16384 spp (= 128^2, "16k")  config camera at 16:9; the 8-GPU workload: rank g of 8 renders
+                                          samples [2048 g, 2048 (g + 1)) of the whole frame (sharding.sample_range)
 and the reference's two remaining scenes with their shipped configs:
   GP      GeometricPrimitives  800x600 256 spp  SphericalPanoramic camera; blocks, cylinders, cones, paraboloids
   BLOCKS  Blocks               800x600 256 spp  three checkered blocks under general Transforms
@@ -20,6 +22,7 @@ WORKLOADS = {
     "C2": dict(scene="CornellBox", image_width=600, aspect_ratio=1.0, samples_per_pixel=1000),
     "C3": dict(scene="Chapter2Final", image_width=800, aspect_ratio=1.0, samples_per_pixel=10000),
     "C4": dict(scene="MeshTest", image_width=1920, aspect_ratio=1920.0 / 1080.0, samples_per_pixel=256, mesh_grid=10),
+    "C5": dict(scene="Chapter2Final", image_width=3840, aspect_ratio=3840.0 / 2160.0, samples_per_pixel=16384),
     "GP": dict(scene="GeometricPrimitives"),
     "BLOCKS": dict(scene="Blocks"),
     "TWO": dict(scene="TwoSpheres"),

@@ -114,6 +114,40 @@ def test_c3_book2_windows_of_the_full_frame(rt, gpu):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def test_c5_book2_4k_one_rank_of_eight(rt, gpu):
+    """BASELINE configs[4]: 3840x2160, 16 384 spp over 8 GPUs.  One GPU here plays rank 5: the head of its sample range on the
+    whole 4K frame, oracle parity on windows of it, and the sum over ranks (all eight ranges, a few samples each, accumulated
+    in rank order as the reduce does) equal to one render of the same samples."""
+    scene, params, camera, sampler = setup(rt, gpu, "C5")
+    assert (params.image_width, params.image_height, sampler.spp) == (3840, 2160, 16384)
+    ranges = [rt.sharding.sample_range(r, 8, sampler.spp) for r in range(8)]
+    assert ranges[5] == (10240, 2048) and sum(n for _, n in ranges) == 16384
+    b5 = ranges[5][0]
+    part, st = gpu.render(params, camera, spp_begin=b5, spp_count=2, stats=True)
+    assert st["paths"] == 3840 * 2160 * 2 and st["medium_tests"] == 2 * st["rays"]
+    assert (part[..., 3] == 2).all() and np.isfinite(part[..., :3]).mean() > 0.9999
+    again, _ = gpu.render(params, camera, spp_begin=b5, spp_count=2)
+    assert np.array_equal(again.view(np.uint32), part.view(np.uint32))
+    tile, _ = gpu.render(params, camera, tile=(3001, 1203, 3130, 1300), spp_begin=b5, spp_count=2)      # a window of it, not on 8-pixel bounds
+    assert np.array_equal(tile[1203:1300, 3001:3130].view(np.uint32), part[1203:1300, 3001:3130].view(np.uint32))
+    oracle = O.OracleScene(scene)
+    for win, s0 in (((1900, 1700, 1924, 1724), b5), ((3816, 2136, 3840, 2160), 16384 - 8), ((0, 0, 24, 24), 0)):
+        oracle_window(rt, gpu, scene, params, camera, sampler, win, spp_begin=s0, spp_count=8, oracle=oracle)
+    # eight ranks, one sample each, summed in rank order == the reduce's result; the RNG is keyed by the absolute sample index,
+    # so each rank's image is a function of its range alone
+    win = (1800, 900, 2056, 1028)
+    total = np.zeros((2160, 3840, 4), np.float32)
+    for b, _ in ranges:
+        one, _ = gpu.render(params, camera, tile=win, spp_begin=b, spp_count=1)
+        total += one
+    acc = np.zeros_like(total)
+    for b, _ in ranges:
+        gpu.render(params, camera, tile=win, spp_begin=b, spp_count=1, out=acc)
+    y0, y1, x0, x1 = win[1], win[3], win[0], win[2]
+    np.testing.assert_allclose(np.nan_to_num(total[y0:y1, x0:x1]), np.nan_to_num(acc[y0:y1, x0:x1]), rtol=1e-5, atol=1e-6)
+    assert (acc[y0:y1, x0:x1, 3] == 8).all() and not acc[:y0].any()
+
+
 def test_c4_mesh_2m_triangles(rt, gpu):
     scene, params, camera, sampler = setup(rt, gpu, "C4")
     f = scene.flatten()

@@ -340,3 +340,11 @@ def test_sample_range_sharding(rt):
             assert b == pos and c >= 0
             pos += c
         assert pos == spp and max(c for _, c in ranges) - min(c for _, c in ranges) <= 1
+
+
+def test_c5_workload_is_the_4k_frame_split_over_eight_ranks(rt):
+    # BASELINE configs[4]: 3840x2160 Book-2 final scene, 16k spp (128^2) sharded over 8 GPUs by sample range
+    name, params, grid = rt.configs.workload("C5")
+    assert (name, params.image_width, params.image_height, params.samples_per_pixel) == ("Chapter2Final", 3840, 2160, 16384)
+    ranges = [rt.sharding.sample_range(r, 8, params.samples_per_pixel) for r in range(8)]
+    assert ranges == [(2048 * r, 2048) for r in range(8)]
