@@ -170,13 +170,13 @@ def main():
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
                          "kernel": "one rt_render call = the wavefront pipeline (rtk::wf_generate_kernel, wf_traverse_kernel, "
-                                   "wf_shade_kernel, wf_fold_kernel; wf_shade_kernel dominates on this workload)",
+                                   "wf_shade_kernel, wf_tail_kernel, wf_fold_kernel; wf_shade_kernel dominates on this workload)",
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
                          "note": "no dense contraction -> FP32 vector roofline (SURVEY.md 8d); flops = work counters x per-unit constants; "
                                  "kernel_ms = HIP events on the caller's stream around the call (the pipelines' streams fork from and join it); "
                                  "traffic = FETCH_SIZE*2 + WRITE_SIZE bytes per step over all kernels, from " + (traffic_src or "n/a")},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # the CPU baseline is an N=1 figure; at N>1 the other ranks would only wait for it
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_ffi as O   # cpu_baseline leg only: the oracle is the checker/baseline, never the product
             cores = min(16, os.cpu_count() or 1)
