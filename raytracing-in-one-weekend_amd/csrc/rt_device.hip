@@ -811,7 +811,8 @@ int rt_synchronize(rt_ctx *ctx, void *stream) {
 int rt_device_info(rt_ctx *ctx, char *name, int32_t name_len, int32_t *cu_count, int32_t *clock_mhz) {
     if (!ctx) return RT_E_INVALID;
     if (name && name_len > 0) {
-        strncpy(name, ctx->prop.name, (size_t)name_len - 1);
+        // some boxes report an empty marketing name: fall back to the ISA name (gfx950:sramecc+:xnack-)
+        strncpy(name, ctx->prop.name[0] ? ctx->prop.name : ctx->prop.gcnArchName, (size_t)name_len - 1);
         name[name_len - 1] = 0;
     }
     if (cu_count) *cu_count = ctx->prop.multiProcessorCount;

@@ -6,7 +6,8 @@ Bars (north_star):
   * images: same scene + seed schedule.  Path geometry is bit-identical (checked through the
     per-pixel ray counters, which must be EQUAL), radiance sums differ only by the association
     of the throughput products: rtol 2e-4 on un-normalised sums, and the resolved 8-bit image
-    may differ by at most 1 LSB in at most 0.1 % of the channels.
+    may differ by at most 1 LSB in at most 0.1 % of the channels; per-pixel RMSE of the
+    resolved [0,1] image below 1e-4.
 """
 import numpy as np
 import pytest
@@ -72,6 +73,10 @@ def compare_images(rt, gpu, oracle, params, camera, sampler, **kw):
     c8 = (np.clip(O.resolve(c_img, spp)[..., :3], 0, 1) * 255).astype(np.int32)
     diff = np.abs(g8 - c8)
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    # north_star's second bar, stated: per-pixel RMSE of the resolved [0,1] image (same scene and seed schedule) < 1e-4
+    g_res, c_res = np.nan_to_num(gpu.resolve(g_img, spp)[..., :3]), np.nan_to_num(O.resolve(c_img, spp)[..., :3])
+    rmse = float(np.sqrt(np.mean((g_res.astype(np.float64) - c_res) ** 2)))
+    assert rmse < 1e-4, rmse
     # the plain (no counters) kernel must give the same sums as the counting variant
     g_plain, _ = gpu.render(params, camera, **kw)
     assert np.array_equal(g_plain.view(np.uint32), g_img.view(np.uint32))
