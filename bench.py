@@ -66,7 +66,7 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("RT_BENCH_FORCE_DIST"):   # the env switch rehearses the RCCL calls with one rank on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
