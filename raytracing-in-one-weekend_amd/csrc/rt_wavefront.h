@@ -141,8 +141,11 @@ RT_DEV void flush_counters(const Counters &cnt, uint32_t paths, unsigned long lo
 // Fills every shard of the next pool buffer behind shade's survivors with new paths and publishes the
 // next iteration's counters.  Thread j looks at pool entry j: items are numbered through the free
 // entries in pool order, so nothing needs an atomic.
+#ifndef RT_WF_GEN_WAVES
+#define RT_WF_GEN_WAVES 1       // min waves per SIMD the generate kernel is compiled for (1 = the compiler's choice: 112 VGPRs, 4 waves)
+#endif
 template <bool STATS>
-__global__ void __launch_bounds__(256) wf_generate_kernel(DScene sc, WfArgs w, PathQ nxt, WfCounters *ctr, uint32_t it,
+__global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScene sc, WfArgs w, PathQ nxt, WfCounters *ctr, uint32_t it,
                                                           float4 *__restrict__ samples, uint32_t *status, unsigned long long *stats,
                                                           uint32_t *pixel_rays) {
     const WfCounters *c = ctr + (it % RT_WF_RING);
