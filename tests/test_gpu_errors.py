@@ -1,0 +1,182 @@
+"""Error behaviour of the C-ABI (include/rt_api.h) on a live context.
+
+The reference panics on a bad scene (an empty `lights` indexes objects[random_int(0,-1)], hittable_list.rs:71-75;
+a non-square spp, sampling.rs:235-251) — a library cannot, so every entry point checks what its kernels will
+index BEFORE anything is launched and returns a status with a message in rt_last_error.  What is tested here:
+each check answers with the documented code, launches nothing, leaves the context usable and the scene that was
+uploaded before in place (the next render gives the same bits), and the caller's buffers untouched.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RT_E_INVALID, RT_E_UNSUPPORTED_PRIMITIVE, RT_E_CANCELLED = -1, -5, -7
+
+
+@pytest.fixture(scope="module")
+def ctx(rt):
+    """A context of its own (the session's one keeps its scene), with C1 (BVH + always-list) uploaded."""
+    b = rt.backend.HipBackend(0)
+    scene, params, camera, sampler = rt.configs.build("C1", image_width=64, samples_per_pixel=4)
+    flat = scene.flatten()
+    yield b, flat, params, camera, sampler
+    b.close()
+
+
+def copy_of(struct):
+    return type(struct).from_buffer_copy(struct)
+
+
+def status_and_text(b, st):
+    return st, b._L.rt_last_error(b._h).decode()
+
+
+def test_render_needs_a_scene_and_a_sampler(rt, ctx):
+    b, flat, params, camera, sampler = ctx
+    b._sampler = sampler
+    with pytest.raises(rt._ffi.RtError) as e:
+        b.render(params, camera)
+    assert e.value.status == RT_E_INVALID and "upload a scene" in str(e.value)
+    info = rt._ffi.rt_scene_info()
+    info.struct_size = C.sizeof(info)
+    assert b._L.rt_scene_query(b._h, C.byref(info)) == RT_E_INVALID
+    b.upload_scene(flat)
+    with pytest.raises(rt._ffi.RtError):          # scene but no sampler yet
+        b.render(params, camera)
+    b.upload_sampler(sampler)
+    img, _ = b.render(params, camera)
+    assert np.all(img[..., 3] == sampler.spp) and np.isfinite(img).all()
+
+
+def test_bad_scene_descriptors_are_refused_and_the_old_scene_stays(rt, ctx):
+    b, flat, params, camera, sampler = ctx
+    b.upload_scene(flat)
+    b.upload_sampler(sampler)
+    ref, _ = b.render(params, camera)
+    n = flat.desc.n_slots
+    assert flat.desc.n_bvh_nodes > 0 and n > 0
+    keep = []                                      # arrays the corrupted descriptors point into
+
+    def with_slot_word(slot, word, value):
+        d = copy_of(flat.desc)
+        a = np.ctypeslib.as_array(flat.desc.slots, shape=(n * 16,)).copy()
+        a.view(np.int32)[slot * 16 + word] = value
+        keep.append(a)
+        d.slots = a.ctypes.data_as(rt._ffi.c_float_p)
+        return d
+
+    def field(**kv):
+        d = copy_of(flat.desc)
+        for k, v in kv.items():
+            setattr(d, k, v)
+        return d
+
+    cases = [
+        (field(struct_size=flat.desc.struct_size - 4), RT_E_INVALID, "descriptor size"),
+        (field(n_lights=0), RT_E_INVALID, "lights"),
+        (field(always_count=n + 1), RT_E_INVALID, "always-list"),
+        (field(bvh_root_ref=int(flat.desc.n_bvh_nodes) + 5), RT_E_INVALID, "bvh_root_ref"),
+        (field(bvh_stack_depth=0), RT_E_INVALID, "bvh_stack_depth"),
+        (field(n_media=5), RT_E_UNSUPPORTED_PRIMITIVE, "ConstantMedium"),
+        (field(slots=None), RT_E_INVALID, "slots missing"),
+        (with_slot_word(n - 1, 5, int(flat.desc.n_materials)), RT_E_INVALID, "material out of range"),
+        (with_slot_word(0, 5, -1), RT_E_INVALID, "material out of range"),
+        (with_slot_word(n // 2, 4, 15), RT_E_UNSUPPORTED_PRIMITIVE, "primitive type"),
+    ]
+    for d, want, text in cases:
+        st, msg = status_and_text(b, b._L.rt_scene_upload(b._h, C.byref(d)))
+        assert st == want and text in msg, (st, msg, text)
+    assert b._L.rt_scene_upload(b._h, None) == RT_E_INVALID
+    again, _ = b.render(params, camera)            # nothing was freed or replaced by the refused uploads
+    assert np.array_equal(again.view(np.uint32), ref.view(np.uint32))
+
+
+def test_a_node_with_a_child_out_of_range_is_found_on_the_host(rt, ctx):
+    b, flat, params, camera, sampler = ctx
+    d = copy_of(flat.desc)
+    nodes = np.ctypeslib.as_array(flat.desc.bvh_nodes, shape=(int(d.n_bvh_nodes) * 16,)).copy()
+    nodes.view(np.int32)[(int(d.n_bvh_nodes) - 1) * 16 + 12] = int(d.n_bvh_nodes)      # inner-node ref one past the end
+    d.bvh_nodes = nodes.ctypes.data_as(rt._ffi.c_float_p)
+    st, msg = status_and_text(b, b._L.rt_scene_upload(b._h, C.byref(d)))
+    assert st == RT_E_INVALID and "child out of range" in msg
+    nodes.view(np.int32)[12] = ~np.int32((int(d.n_slots) << 3) | 1)                      # leaf run starting past the last slot
+    st, msg = status_and_text(b, b._L.rt_scene_upload(b._h, C.byref(d)))
+    assert st == RT_E_INVALID and "child out of range" in msg
+
+
+def test_bad_sampler_tables_are_refused(rt, ctx):
+    b, flat, params, camera, sampler = ctx
+    d = copy_of(sampler.desc)
+    d.sets = 0
+    assert b._L.rt_sampler_upload(b._h, C.byref(d)) == RT_E_INVALID
+    d = copy_of(sampler.desc)
+    count = int(d.sets) * int(d.samples_in_set)
+    idx = np.ctypeslib.as_array(sampler.desc.shuffled_indices, shape=(count,)).copy()
+    idx[count // 2] = d.samples_in_set             # the kernels index samples[set][shuffled]: one past the end
+    d.shuffled_indices = idx.ctypes.data_as(rt._ffi.c_u32_p)
+    st, msg = status_and_text(b, b._L.rt_sampler_upload(b._h, C.byref(d)))
+    assert st == RT_E_INVALID and "shuffled index" in msg
+
+
+def test_bad_render_parameters_leave_the_image_alone(rt, ctx):
+    b, flat, params, camera, sampler = ctx
+    b.upload_scene(flat)
+    b.upload_sampler(sampler)
+    good, W, H = b._params(params, camera, 0x5EED, 0, None, None, None, None)
+    good.out_location = rt._ffi.RT_MEM_HOST
+    out = np.full((H, W, 4), 7.0, np.float32)
+    stats = rt._ffi.rt_stats()
+
+    def call(p, out_ptr=None, st=None):
+        return status_and_text(b, b._L.rt_render(b._h, C.byref(p), out.ctypes.data if out_ptr is None else out_ptr, st))
+
+    def changed(**kv):
+        p = copy_of(good)
+        for k, v in kv.items():
+            setattr(p, k, v)
+        return p
+
+    cancel = C.c_int32(1)
+    cases = [
+        (changed(struct_size=good.struct_size + 8), RT_E_INVALID, "bad arguments"),
+        (changed(image_width=1), RT_E_INVALID, "at least 2x2"),
+        (changed(image_width=1 << 16, image_height=1 << 15), RT_E_INVALID, "too large"),
+        (changed(samples_per_pixel=sampler.spp + 1), RT_E_INVALID, "does not match the sampler"),
+        (changed(spp_begin=2, spp_count=sampler.spp), RT_E_INVALID, "sample range"),
+        (changed(spp_begin=-1), RT_E_INVALID, "sample range"),
+        (changed(projection=9), RT_E_INVALID, "projection"),
+        (changed(collect_stats=1), RT_E_INVALID, "stats"),
+        (changed(cancel=C.pointer(cancel)), RT_E_CANCELLED, "cancelled"),
+    ]
+    for p, want, text in cases:
+        st, msg = call(p)
+        assert st == want and text in msg, (st, msg, text)
+    assert b._L.rt_render(b._h, C.byref(good), None, None) == RT_E_INVALID          # no output buffer
+    assert b._L.rt_render(b._h, None, out.ctypes.data, None) == RT_E_INVALID
+    assert np.all(out == 7.0)
+    # a tile outside the image is empty, one that overlaps it is clipped: both are fine (main.rs:1326-1352 clips its blocks too)
+    assert call(changed(tile_x0=W, tile_x1=W + 8))[0] == 0 and np.all(out == 7.0)
+    out[:] = 0.0
+    assert call(changed(tile_x0=W - 8, tile_x1=W + 100, tile_y0=-5, tile_y1=4))[0] == 0
+    full, _ = b.render(params, camera)
+    assert np.array_equal(out[:4, W - 8:].view(np.uint32), full[:4, W - 8:].view(np.uint32))
+    out[:4, W - 8:] = 0.0
+    assert np.all(out == 0.0)
+    cancel.value = 0                                # a cancel flag that stays 0 changes nothing
+    st, _ = call(changed(cancel=C.pointer(cancel)), st=C.byref(stats))
+    assert st == 0 and np.array_equal(out.view(np.uint32), full.view(np.uint32))
+
+
+def test_resolve_and_first_hit_argument_checks(rt, ctx):
+    b, flat, params, camera, sampler = ctx
+    s = np.ones((4, 4), np.float32)
+    o = np.zeros_like(s)
+    assert b._L.rt_resolve(b._h, s.ctypes.data, 4, 0, o.ctypes.data, rt._ffi.RT_MEM_HOST, None) == RT_E_INVALID    # spp 0 divides by zero
+    assert b._L.rt_resolve(b._h, None, 4, 4, o.ctypes.data, rt._ffi.RT_MEM_HOST, None) == RT_E_INVALID
+    assert b._L.rt_resolve(b._h, s.ctypes.data, -1, 4, o.ctypes.data, rt._ffi.RT_MEM_HOST, None) == RT_E_INVALID
+    assert np.all(o == 0.0)
+    pid, t, nrm, ff, uv = b.trace_first_hit(np.zeros((7, 0), np.float32))             # no rays: nothing to do, no launch
+    assert len(pid) == 0
