@@ -263,6 +263,17 @@ int rt_resolve_rgb8(rt_ctx *ctx, const float *rgba_sum, int32_t n_pixels, int32_
 int rt_trace_first_hit(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_min, float t_max,
                        uint32_t *prim_id, float *t, float *normal3, uint8_t *front_face, float *uv2);
 
+/* rt_trace_first_hit for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, same kernel, same results; the staging
+ * of rays and results and the traversal-stack overflow live in a static device array of RT_NOALLOC_SCRATCH_BYTES per GPU
+ * (held from library load to process exit) instead of a buffer allocated per call, and the call makes no hipMalloc / hipFree.
+ * n is limited by that array: 57 bytes per ray plus 4 bytes per ray and BVH stack level beyond 48 (about 147 000 rays for the
+ * BASELINE scenes); a larger batch returns RT_E_INVALID with the limit in rt_last_error() and touches nothing.
+ * All contexts of one GPU share its array: calls that overlap in time on one GPU race (serialise them). */
+#define RT_NOALLOC_SCRATCH_BYTES (8u << 20)
+int rt_trace_first_hit_noalloc(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_min, float t_max,
+                               uint32_t *prim_id, float *t, float *normal3, uint8_t *front_face, float *uv2);
+
 /* Block until everything queued on `stream` (NULL = default) by this context is done. */
 int rt_synchronize(rt_ctx *ctx, void *stream);
 

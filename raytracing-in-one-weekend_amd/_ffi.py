@@ -179,6 +179,7 @@ HOST_SYMBOLS = [
 HIP_SYMBOLS = [
     "rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_scene_upload", "rt_sampler_upload", "rt_render",
     "rt_resolve", "rt_trace_first_hit", "rt_synchronize", "rt_device_info", "rt_scene_query", "rt_scene_read_bvh", "rt_resolve_rgb8",
+    "rt_trace_first_hit_noalloc",
 ]
 
 _host = None
@@ -286,6 +287,7 @@ def hip_lib():
     L.rt_resolve_rgb8.argtypes = [vp, C.c_void_p, i32, i32, C.c_void_p, i32, vp]
     L.rt_trace_first_hit.argtypes = [vp, c_float_p, i32, C.c_float, C.c_float, c_u32_p, c_float_p, c_float_p, c_u8_p,
                                      c_float_p]
+    L.rt_trace_first_hit_noalloc.argtypes = L.rt_trace_first_hit.argtypes
     L.rt_synchronize.argtypes = [vp, vp]
     L.rt_device_info.argtypes = [vp, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32)]
     _hip = L

@@ -117,13 +117,15 @@ class HipBackend:
     def resolve_device(self, sum_ptr, n_pixels, spp, out_ptr, stream_ptr=None):
         self._check(self._L.rt_resolve(self._h, sum_ptr, n_pixels, spp, out_ptr, _ffi.RT_MEM_DEVICE, stream_ptr))
 
-    def trace_first_hit(self, rays_soa, t_min=0.001, t_max=float("inf")):
+    def trace_first_hit(self, rays_soa, t_min=0.001, t_max=float("inf"), no_alloc=False):
+        """rt_trace_first_hit; no_alloc=True calls rt_trace_first_hit_noalloc (static device scratch, no hipMalloc)."""
         rays_soa = np.ascontiguousarray(rays_soa, np.float32)
         assert rays_soa.ndim == 2 and rays_soa.shape[0] == 7
         n = rays_soa.shape[1]
         pid = np.zeros(n, np.uint32); t = np.zeros(n, np.float32); nrm = np.zeros((n, 3), np.float32)
         ff = np.zeros(n, np.uint8); uv = np.zeros((n, 2), np.float32)
-        self._check(self._L.rt_trace_first_hit(
+        fn = self._L.rt_trace_first_hit_noalloc if no_alloc else self._L.rt_trace_first_hit
+        self._check(fn(
             self._h, rays_soa.ctypes.data_as(_ffi.c_float_p), n, t_min, t_max, pid.ctypes.data_as(_ffi.c_u32_p),
             t.ctypes.data_as(_ffi.c_float_p), nrm.ctypes.data_as(_ffi.c_float_p), ff.ctypes.data_as(_ffi.c_u8_p),
             uv.ctypes.data_as(_ffi.c_float_p)))

@@ -42,9 +42,19 @@ struct rt_ctx {
     hipStream_t wf_stream[4] = {};                              // one per pipeline (render_wavefront)
     hipEvent_t wf_event[4][2] = {};
     hipEvent_t wf_fork = nullptr, wf_join[4] = {};
+    char *noalloc_scratch = nullptr;   // = g_noalloc_ptr[device]
 };
 
+// Scratch of rt_trace_first_hit_noalloc (rt_api.h): staging of the rays and results plus the traversal-stack overflow, in a
+// static device array instead of a hipMalloc'd buffer.  Every GPU the library runs on holds its own copy at its own address
+// until the process ends.  In host code this name is only a handle for hipGetSymbolAddress: the address kernels and copies
+// use is the one rt_create looks up per device (g_noalloc_ptr), never the name itself.
+static __device__ __align__(256) unsigned char g_noalloc_scratch[RT_NOALLOC_SCRATCH_BYTES];
+
 namespace {
+
+constexpr int kMaxDevices = 64;
+void *g_noalloc_ptr[kMaxDevices] = {};   // device address of g_noalloc_scratch on each device (set once by rt_create, same value every time)
 
 thread_local std::string g_create_error;
 
@@ -329,6 +339,11 @@ int rt_create(int device_id, rt_ctx **out) {
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_stats, 64 * sizeof(unsigned long long));
+    if (e == hipSuccess && device_id < kMaxDevices) {   // this device's copy of the static scratch array (device_id is current)
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch));
+        if (e == hipSuccess) { g_noalloc_ptr[device_id] = p; ctx->noalloc_scratch = static_cast<char *>(p); }
+    }
     if (e != hipSuccess) {
         int st = fail(nullptr, RT_E_HIP, "rt_create: %s", hipGetErrorString(e));
         delete ctx;
@@ -762,6 +777,46 @@ int rt_resolve_rgb8(rt_ctx *ctx, const float *rgba_sum, int32_t n_pixels, int32_
     return RT_OK;
 }
 
+// Layout of the device buffer a first-hit query works in: rays 28N | prim 4N | t 4N | normal 12N | uv 8N | ff N | stack overflow
+struct FirstHitLayout {
+    size_t N, off_prim, off_t, off_n, off_uv, off_ff, off_ovf, ovf_bytes, total, n_threads;
+    uint32_t lds_depth;
+};
+static FirstHitLayout first_hit_layout(const rt_ctx *ctx, int32_t n) {
+    FirstHitLayout L{};
+    L.N = (size_t)n;
+    // traversal stack: up to 48 entries per lane in LDS (48 KB per block), a deeper tree's rest in HBM
+    L.lds_depth = ctx->stack_depth < 48u ? ctx->stack_depth : 48u;
+    L.n_threads = (L.N + 255) / 256 * 256;
+    L.ovf_bytes = (size_t)(ctx->stack_depth - L.lds_depth) * L.n_threads * sizeof(StackEntry);
+    L.off_prim = 28 * L.N; L.off_t = 32 * L.N; L.off_n = 36 * L.N; L.off_uv = 48 * L.N; L.off_ff = 56 * L.N;
+    L.off_ovf = (57 * L.N + 255) / 256 * 256;
+    L.total = L.off_ovf + L.ovf_bytes;
+    return L;
+}
+// Stage the rays into d, run first_hit_kernel, copy the results back, wait.  d holds L.total bytes; nothing is allocated here.
+static hipError_t first_hit_run(rt_ctx *ctx, char *d, const FirstHitLayout &L, const float *rays_soa, int32_t n, float t_min, float t_max,
+                                uint32_t *prim_id, float *t, float *normal3, uint8_t *front_face, float *uv2) {
+    const size_t N = L.N;
+    hipStream_t stream = ctx->stream;
+    hipError_t e = hipMemcpyAsync(d, rays_soa, 28 * N, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        dim3 grid((unsigned)((N + 255) / 256)), block(256);
+        size_t lds = (size_t)L.lds_depth * 256 * sizeof(StackEntry);
+        hipLaunchKernelGGL(first_hit_kernel, grid, block, lds, stream, ctx->sc, (const float *)d, n, t_min, t_max,
+                           (uint32_t *)(d + L.off_prim), (float *)(d + L.off_t), (float *)(d + L.off_n), (uint8_t *)(d + L.off_ff),
+                           (float *)(d + L.off_uv), L.lds_depth, L.ovf_bytes ? (StackEntry *)(d + L.off_ovf) : nullptr, (uint32_t)L.n_threads);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(prim_id, d + L.off_prim, 4 * N, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t, d + L.off_t, 4 * N, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(normal3, d + L.off_n, 12 * N, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(front_face, d + L.off_ff, N, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && uv2) e = hipMemcpyAsync(uv2, d + L.off_uv, 8 * N, hipMemcpyDeviceToHost, stream);
+    hipError_t e2 = hipStreamSynchronize(stream);   // also after a failed copy: nothing of this call may still be in flight
+    return e != hipSuccess ? e : e2;
+}
+
 int rt_trace_first_hit(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_min, float t_max, uint32_t *prim_id, float *t,
                        float *normal3, uint8_t *front_face, float *uv2) {
     if (!ctx) return RT_E_INVALID;
@@ -770,32 +825,36 @@ int rt_trace_first_hit(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_mi
     if (n == 0) return RT_OK;
     int st = set_device(ctx);
     if (st) return st;
-    size_t N = (size_t)n;
+    const FirstHitLayout L = first_hit_layout(ctx, n);
     char *d = nullptr;
-    // traversal stack: up to 48 entries per lane in LDS (48 KB per block), a deeper tree's rest in HBM
-    const uint32_t lds_depth = ctx->stack_depth < 48u ? ctx->stack_depth : 48u;
-    const size_t n_threads = (N + 255) / 256 * 256, ovf_bytes = (size_t)(ctx->stack_depth - lds_depth) * n_threads * sizeof(StackEntry);
-    // one allocation: rays 28N | prim 4N | t 4N | normal 12N | uv 8N | ff N | stack overflow
-    size_t off_prim = 28 * N, off_t = 32 * N, off_n = 36 * N, off_uv = 48 * N, off_ff = 56 * N, off_ovf = (57 * N + 255) / 256 * 256, total = off_ovf + ovf_bytes;
-    HIP_TRY(ctx, hipMalloc((void **)&d, total));
-    hipStream_t stream = ctx->stream;
-    hipError_t e = hipMemcpyAsync(d, rays_soa, 28 * N, hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) {
-        dim3 grid((unsigned)((N + 255) / 256)), block(256);
-        size_t lds = (size_t)lds_depth * 256 * sizeof(StackEntry);
-        hipLaunchKernelGGL(first_hit_kernel, grid, block, lds, stream, ctx->sc, (const float *)d, n, t_min, t_max,
-                           (uint32_t *)(d + off_prim), (float *)(d + off_t), (float *)(d + off_n), (uint8_t *)(d + off_ff),
-                           (float *)(d + off_uv), lds_depth, ovf_bytes ? (StackEntry *)(d + off_ovf) : nullptr, (uint32_t)n_threads);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(prim_id, d + off_prim, 4 * N, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(t, d + off_t, 4 * N, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(normal3, d + off_n, 12 * N, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(front_face, d + off_ff, N, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess && uv2) e = hipMemcpyAsync(uv2, d + off_uv, 8 * N, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    HIP_TRY(ctx, hipMalloc((void **)&d, L.total));
+    hipError_t e = first_hit_run(ctx, d, L, rays_soa, n, t_min, t_max, prim_id, t, normal3, front_face, uv2);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(ctx, RT_E_HIP, "rt_trace_first_hit: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+// rt_trace_first_hit without an allocation: the same kernel on the same layout, in this device's copy of g_noalloc_scratch.
+// Nothing in the scratch has to start at zero (the kernel writes every result of rays 0..n-1 and pushes before it pops), so
+// the previous call's contents are simply overwritten; calls that overlap on one GPU would race on it.
+int rt_trace_first_hit_noalloc(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_min, float t_max, uint32_t *prim_id, float *t,
+                               float *normal3, uint8_t *front_face, float *uv2) {
+    if (!ctx) return RT_E_INVALID;
+    if (!rays_soa || n < 0 || !prim_id || !t || !normal3 || !front_face) return fail(ctx, RT_E_INVALID, "rt_trace_first_hit_noalloc: bad arguments");
+    if (!ctx->have_scene) return fail(ctx, RT_E_INVALID, "rt_trace_first_hit_noalloc: upload a scene first");
+    if (!ctx->noalloc_scratch) return fail(ctx, RT_E_HIP, "rt_trace_first_hit_noalloc: no scratch address for device %d", ctx->device);
+    if (n == 0) return RT_OK;
+    const FirstHitLayout L = first_hit_layout(ctx, n);
+    if (L.total > (size_t)RT_NOALLOC_SCRATCH_BYTES) {
+        const size_t per_ray = 57 + (size_t)(ctx->stack_depth - L.lds_depth) * sizeof(StackEntry);
+        return fail(ctx, RT_E_INVALID, "rt_trace_first_hit_noalloc: %d rays need %zu bytes of scratch, the static array holds %u "
+                    "(about %zu rays with this scene's BVH); split the batch or use rt_trace_first_hit",
+                    n, L.total, (unsigned)RT_NOALLOC_SCRATCH_BYTES, ((size_t)RT_NOALLOC_SCRATCH_BYTES - 512) / per_ray / 256 * 256);
+    }
+    int st = set_device(ctx);
+    if (st) return st;
+    hipError_t e = first_hit_run(ctx, ctx->noalloc_scratch, L, rays_soa, n, t_min, t_max, prim_id, t, normal3, front_face, uv2);
+    if (e != hipSuccess) return fail(ctx, RT_E_HIP, "rt_trace_first_hit_noalloc: %s", hipGetErrorString(e));
     return RT_OK;
 }
 
