@@ -1,18 +1,29 @@
-"""bench.py — Mrays/s of the HIP path tracer on the BASELINE.json workload.
+"""bench.py — Mrays/s of the HIP path tracer on the BASELINE.json workloads.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C1] [--spp S] [--no-cpu] [--no-sub]
 
-A step = one full frame of the workload: every pixel, every sample, depth 50, accumulated into
-an HBM-resident W*H*4 f32 buffer (scene, BVH and sampler tables are resident before the timed
-region).  N=1: Cornell box 600x600 at 1000 spp (BASELINE.json configs[1]).  N>1: one process
-per GPU; rank g renders samples [g*S, (g+1)*S) of an N*S-spp frame (S = 1000) and the per-GPU
-sums are added on rank 0 by one RCCL reduce inside the timed region ("weak": per-GPU work is fixed).
-A ray = one closest-hit query issued by ray_color (camera.rs:264).  The number of rays per step
-is a constant of (scene, seed) and is counted once, untimed, by the counting kernel variant.
+A step = one full frame of the workload: every pixel, every sample, depth 50, accumulated into an HBM-resident
+W*H*4 f32 buffer (scene, BVH and sampler tables are resident before the timed region).
+
+Headline (`value`, N=1): **C1**, the Book-1 final scene 1200x675 at 10 spp — the configuration BASELINE.json's target
+(>= 100x the host CPU at 1 GPU) is stated on; its BVH walk is the path north_star is about.  The same JSON line carries
+a `workloads` dict with the other single-GPU configurations at their FULL sizes — C2 Cornell box 600x600 at 1000 spp,
+C3 Book-2 final scene 800x800 at 10 000 spp, C4 triangle-mesh scene 1920x1080 at 256 spp over 2.26 M triangles — each
+with ms_per_step, Mrays/s, its roofline fraction and node_visits_per_ray, measured the same way (`--no-sub` skips them).
+
+N>1: one process per GPU (the driver launches torch.distributed.run; run without a launcher, `--gpus N` spawns the N
+ranks itself before anything touches a GPU).  Weak scaling: rank g renders samples [g*S, (g+1)*S) of an N*S-spp frame
+(S = the workload's spp) and the per-GPU sums are added on rank 0 by one RCCL reduce inside the timed region.
+`--strong` keeps the frame fixed instead (the workload's spp split over the ranks; BASELINE's C5 is such a frame).
+
+A ray = one closest-hit query issued by ray_color (camera.rs:264).  The number of rays per step is a constant of
+(scene, seed) and is counted once, untimed, by the counting kernel variant, which traces the identical paths.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -30,9 +41,14 @@ F_SHADE = [140, 45, 60, 2, 20]      # lambertian+mixture pdf, metal, dielectric,
 F_TEX = [0, 8, 1000, 12]            # solid, checker, noise (7 octaves), image
 F_CAMERA = 40
 PEAK_FP32_VALU_TFLOPS = 157.3       # MI355X_MICROARCH.md "Peak FP32 (vector)"
+PROFILE_ROUND = "r2"
+
+# sub-workloads of the default run: (name, timed steps, warm-up steps).  C3's frame is 6.4e9 paths: one timed step.
+SUB_WORKLOADS = (("C2", 3, 1), ("C3", 1, 0), ("C4", 3, 1))
 
 
 def algorithmic_flops(st):
+    """counters x constants: box tests are the child boxes actually tested (rt_stats.box_tests)."""
     pt = st["prim_tests"]
     f = st["box_tests"] * F_BOX + st["rays"] * F_RAY
     f += pt[0] * F_SPHERE + pt[1] * (F_SPHERE + F_MOVING_EXTRA) + (pt[2] + pt[3] + pt[4]) * F_RECT + pt[5] * F_TRI + sum(pt[6:]) * F_QUADRIC
@@ -42,159 +58,246 @@ def algorithmic_flops(st):
     return f
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="C2")
-    ap.add_argument("--width", type=int, default=0)
-    ap.add_argument("--spp", type=int, default=0)
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--device-bvh", nargs="?", const="ploc", default=None, choices=["ploc", "lbvh"],
-                    help="build the BVH on the GPU (rt_bvh_build.hip) instead of on the host: clustering (default) or Morton radix tree")
-    args = ap.parse_args()
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: start the N ranks as child processes (this process has not touched a GPU
+    and never will) and exit with the worst of their codes.  Rank 0's JSON line is the children's stdout."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
 
-    import numpy as np
-    import torch
-    import rtiow_loader
-    rt = rtiow_loader.load()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    dist = None
-    if world > 1 or os.environ.get("RT_BENCH_FORCE_DIST"):   # the env switch rehearses the RCCL calls with one rank on a 1-GPU box
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+class Bench:
+    def __init__(self, args, rt, torch, dist, rank, local_rank, world):
+        self.args, self.rt, self.torch, self.dist = args, rt, torch, dist
+        self.rank, self.world = rank, world
+        self.dev = torch.device("cuda", local_rank)
+        self.gpu = rt.backend.HipBackend(local_rank)   # raises if the HIP library or the GPU is missing
+        self.stream = torch.cuda.current_stream(self.dev)
 
-    over = {}
-    if args.width:
-        over["image_width"] = args.width
-    base_spp = args.spp or rt.configs.WORKLOADS[args.workload]["samples_per_pixel"]
-    total_spp = base_spp * world
-    over["samples_per_pixel"] = total_spp
-    scene, params, camera, sampler = rt.configs.build(args.workload, **over)
-    W, H = params.image_width, params.image_height
-    gpu = rt.backend.HipBackend(local_rank)   # raises if the HIP library or the GPU is missing
-    t_flat = time.perf_counter()
-    flat = scene.flatten(device_bvh=args.device_bvh is not None)
-    t_flat = time.perf_counter() - t_flat
-    if args.device_bvh == "lbvh" and flat.desc.build_bvh_on_device:
-        flat.desc.build_bvh_on_device = 2      # RT_BVH_DEVICE_LBVH
-    gpu.upload_scene(flat)
-    info = gpu.scene_info()
-    gpu.upload_sampler(sampler)
-    spp_begin, spp_count = rank * base_spp, base_spp
+    def run(self, name, steps, warmup, spp=0, width=0, cpu=False):
+        """One workload: upload, count rays (untimed), warm up, time `steps` frames.  Returns the result dict."""
+        args, rt, torch, dist, gpu, dev = self.args, self.rt, self.torch, self.dist, self.gpu, self.dev
+        import numpy as np
+        over = {}
+        if width:
+            over["image_width"] = width
+        base_spp = spp or rt.configs.WORKLOADS[name]["samples_per_pixel"]
+        if args.strong:
+            total_spp = base_spp
+            spp_begin, spp_count = rt.sharding.sample_range(self.rank, self.world, total_spp)
+        else:
+            total_spp = base_spp * self.world
+            spp_begin, spp_count = self.rank * base_spp, base_spp
+        over["samples_per_pixel"] = total_spp
+        t_build = time.perf_counter()
+        scene, params, camera, sampler = rt.configs.build(name, **over)
+        t_build = time.perf_counter() - t_build
+        W, H = params.image_width, params.image_height
+        t_flat = time.perf_counter()
+        flat = scene.flatten(device_bvh=args.device_bvh is not None)
+        t_flat = time.perf_counter() - t_flat
+        if args.device_bvh == "lbvh" and flat.desc.build_bvh_on_device:
+            flat.desc.build_bvh_on_device = 2      # RT_BVH_DEVICE_LBVH
+        gpu.upload_scene(flat)
+        info = gpu.scene_info()
+        gpu.upload_sampler(sampler)
 
-    acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    sptr = stream.cuda_stream
+        acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+        sptr = self.stream.cuda_stream
 
-    def step():
-        acc.zero_()
-        gpu.render_device(params, camera, acc.data_ptr(), sptr, spp_begin=spp_begin, spp_count=spp_count)
+        # rays per step: counted once by the counting variant (same paths, same seed), untimed; its image is the check below
+        count_img = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+        st = gpu.render_device_stats(params, camera, count_img.data_ptr(), sptr, spp_begin=spp_begin, spp_count=spp_count)
+        rays_step = torch.tensor([st["rays"], st["paths"]], dtype=torch.float64, device=dev)
         if dist is not None:
-            dist.reduce(acc, dst=0)   # RCCL over xGMI: per-GPU sums -> rank 0
+            dist.all_reduce(rays_step)
+        total_rays, total_paths = float(rays_step[0].item()), float(rays_step[1].item())
 
-    # rays per step: counted once by the counting variant (same paths, same seed), untimed
-    host_img = np.zeros((H, W, 4), np.float32)
-    _, st = gpu.render(params, camera, spp_begin=spp_begin, spp_count=spp_count, out=host_img, stats=True)
-    rays_step = torch.tensor([st["rays"], st["paths"]], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(rays_step)
-    total_rays, total_paths = float(rays_step[0].item()), float(rays_step[1].item())
+        def step():
+            acc.zero_()
+            gpu.render_device(params, camera, acc.data_ptr(), sptr, spp_begin=spp_begin, spp_count=spp_count)
+            if dist is not None:
+                dist.reduce(acc, dst=0)   # RCCL over xGMI: per-GPU sums -> rank 0
 
-    for _ in range(args.warmup):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        acc.zero_()
-        ev[k][0].record(stream)
-        gpu.render_device(params, camera, acc.data_ptr(), sptr, spp_begin=spp_begin, spp_count=spp_count)
-        ev[k][1].record(stream)
+        for _ in range(warmup):
+            step()
         if dist is not None:
-            dist.reduce(acc, dst=0)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-
-    if rank == 0:
-        # sanity: the device image of the last step equals the counted host render (world 1) / is finite
-        img = acc.cpu().numpy()
-        if world == 1:
-            assert np.array_equal(np.nan_to_num(img), np.nan_to_num(host_img)), "timed kernel and counting kernel disagree"
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for k in range(steps):
+            acc.zero_()
+            ev[k][0].record(self.stream)
+            gpu.render_device(params, camera, acc.data_ptr(), sptr, spp_begin=spp_begin, spp_count=spp_count)
+            ev[k][1].record(self.stream)
+            if dist is not None:
+                dist.reduce(acc, dst=0)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        if self.rank != 0:
+            return None
+        # sanity: the timed kernels' image equals the counting variant's, bit for bit (world 1: nothing was reduced into it)
+        if self.world == 1:
+            a, b = acc.cpu().numpy(), count_img.cpu().numpy()
+            assert np.array_equal(np.nan_to_num(a), np.nan_to_num(b)), "timed kernel and counting kernel disagree"
+        del acc, count_img
         flops = algorithmic_flops(st)
         # HBM-side bytes per step: PMC passes of this very workload (tools/pmc.sh), committed under profiles/
         traffic, traffic_src = None, None
-        prof = os.path.join(ROOT, "profiles", "r1", "%s_%dspp_pmc.json" % (args.workload.lower(), base_spp))
-        if world == 1 and not args.width and os.path.exists(prof):
+        prof = os.path.join(ROOT, "profiles", PROFILE_ROUND, "%s_%dspp_pmc.json" % (name.lower(), base_spp))
+        if self.world == 1 and not width and os.path.exists(prof):
             with open(prof) as f:
                 ks = json.load(f)["kernels"].values()
             traffic = sum(2.0 * (k.get("fetch_size_kb") or 0.0) + (k.get("write_size_kb") or 0.0) for k in ks) * 1024.0
             traffic_src = os.path.relpath(prof, ROOT)
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         out = {
-            "metric": "Mrays/sec", "value": total_rays * args.steps / elapsed / 1e6, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value": total_rays * steps / elapsed / 1e6, "unit": "Mrays/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
             "config": {"workload": "%s %s %dx%d, %d spp per GPU (%d total), depth %d" % (
-                args.workload, rt.configs.WORKLOADS[args.workload]["scene"], W, H, base_spp, total_spp, params.max_ray_depth),
-                "sharding": "sample ranges per GPU + RCCL reduce to rank 0" if world > 1 else "single GPU",
+                name, rt.configs.WORKLOADS[name]["scene"], W, H, spp_count, total_spp, params.max_ray_depth),
+                "sharding": ("sample ranges per GPU + RCCL reduce to rank 0" + (", fixed frame" if args.strong else "")) if self.world > 1 else "single GPU",
                 "seed": rt.configs.SEED, "primitives": int(flat.desc.n_prims), "bvh_nodes": int(info["n_bvh_nodes"]),
-                       "bvh": "built on the GPU (%s) in %.2f ms (host flatten %.2f s)" % (args.device_bvh, info["bvh_build_ms"], t_flat) if info["built_on_device"]
-                              else "built on the host in %.2f s (flatten)" % t_flat},
-            "rays_per_step": total_rays, "paths_per_step": total_paths, "node_visits_per_ray": round(st["node_visits"] / max(1, st["rays"]), 2),
-            "mpaths_per_s": total_paths * args.steps / elapsed / 1e6,
+                "bvh": "built on the GPU (%s) in %.2f ms (host flatten %.2f s)" % (args.device_bvh, info["bvh_build_ms"], t_flat) if info["built_on_device"]
+                       else "built on the host in %.2f s (flatten)" % t_flat},
+            "rays_per_step": total_rays, "paths_per_step": total_paths,
+            "node_visits_per_ray": round(st["node_visits"] / max(1, st["rays"]), 2),
+            "box_tests_per_ray": round(st["box_tests"] / max(1, st["rays"]), 2),
+            "mpaths_per_s": total_paths * steps / elapsed / 1e6,
             # lane occupancy per kernel phase (counting variant): lanes working / lanes issued
             "phase_occupancy": {n: (round(l / s_, 4) if s_ else None) for n, l, s_ in zip(
                 ("node_step", "leaf_step", "shade", "path_start", "begin_trace"), st["phase_lanes"], st["phase_slots"])},
-            "phase_wave_runs_per_ray": {n: round(s_ / 64.0 / max(st["rays"], 1) * 64, 3) for n, s_ in zip(
-                ("node_step", "leaf_step", "shade", "path_start", "begin_trace"), st["phase_slots"])},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
                          "kernel": "one rt_render call = the wavefront pipeline (rtk::wf_generate_kernel, wf_traverse_kernel, "
-                                   "wf_shade_kernel, wf_tail_kernel, wf_fold_kernel; wf_shade_kernel dominates on this workload)",
+                                   "wf_shade_kernel, wf_tail_kernel, wf_fold_kernel)",
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
                          "note": "no dense contraction -> FP32 vector roofline (SURVEY.md 8d); flops = work counters x per-unit constants; "
                                  "kernel_ms = HIP events on the caller's stream around the call (the pipelines' streams fork from and join it); "
                                  "traffic = FETCH_SIZE*2 + WRITE_SIZE bytes per step over all kernels, from " + (traffic_src or "n/a")},
         }
-        if not args.no_cpu and world == 1:      # the CPU baseline is an N=1 figure; at N>1 the other ranks would only wait for it
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_ffi as O   # cpu_baseline leg only: the oracle is the checker/baseline, never the product
-            cores = min(16, os.cpu_count() or 1)
-            oracle = O.OracleScene(scene)
+        if cpu:
+            out.update(self.cpu_baseline(scene, params, camera, sampler, W, H, total_spp, out["value"]))
+        return out
+
+    def cpu_baseline(self, scene, params, camera, sampler, W, H, total_spp, gpu_value):
+        """the CPU port (oracle/) on all host cores and on one core, median of 3 runs each, on a bounded sample
+        of the same workload (whole frame, the first k samples per pixel; k sized to ~6 s per all-core run)."""
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_ffi as O   # cpu_baseline leg only: the oracle is the checker/baseline, never the product
+        nproc = os.cpu_count() or 1
+        cores = min(16, nproc)   # the GPU box gives one GPU's share of the host: 16 threads
+        oracle = O.OracleScene(scene)
+
+        def timed(spp_count, threads, tile=None):
             c0 = time.perf_counter()
-            _, cal_rays = oracle.render(params, camera, sampler, spp_begin=0, spp_count=1, threads=cores)   # calibration, untimed
-            cal = time.perf_counter() - c0
-            sample_spp = max(1, min(base_spp, int(15.0 / max(cal, 1e-3))))                                   # about 15 s of CPU work
-            c0 = time.perf_counter()
-            _, c_rays = oracle.render(params, camera, sampler, spp_begin=0, spp_count=sample_spp, threads=cores)
-            c_dt = time.perf_counter() - c0
-            out["cpu_baseline"] = {"value": c_rays / c_dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-                                   "sample": "%dx%d, samples 0..%d of %d, depth %d, %d threads, %.1f s" % (
-                                       W, H, sample_spp, total_spp, params.max_ray_depth, cores, c_dt)}
-            out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+            _, rays = oracle.render(params, camera, sampler, spp_begin=0, spp_count=spp_count, threads=threads, **({"tile": tile} if tile else {}))
+            dt = time.perf_counter() - c0
+            return rays / dt / 1e6, dt
+
+        _, cal = timed(1, cores)                                     # calibration, untimed
+        k_all = max(1, min(total_spp, int(6.0 / max(cal, 1e-3))))
+        runs_all = [timed(k_all, cores) for _ in range(3)]
+        # one core: the same frame's top rows (a 1/8 strip), 1 sample or more, ~4 s per run
+        strip = (0, 0, W, max(8, H // 8))
+        _, cal1 = timed(1, 1, strip)
+        k_one = max(1, min(total_spp, int(4.0 / max(cal1, 1e-3))))
+        runs_one = [timed(k_one, 1, strip) for _ in range(3)]
+        v_all, v_one = statistics.median(r[0] for r in runs_all), statistics.median(r[0] for r in runs_one)
+        return {
+            "cpu_baseline": {"value": v_all, "unit": "Mrays/s", "cores": cores, "kind": "port", "nproc": nproc,
+                             "runs": [round(r[0], 3) for r in runs_all], "one_core": {"value": v_one, "runs": [round(r[0], 3) for r in runs_one],
+                                      "sample": "rows 0..%d of the frame, samples 0..%d, 1 thread, %.1f s per run" % (strip[3], k_one, runs_one[0][1])},
+                             "sample": "%dx%d whole frame, samples 0..%d of %d, depth %d, %d threads, median of 3 runs of %.1f s" % (
+                                 W, H, k_all, total_spp, params.max_ray_depth, cores, runs_all[0][1])},
+            "speedup_vs_cpu_port": gpu_value / v_all,
+        }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C1")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-sub", action="store_true", help="skip the C2 / C3 / C4 sub-workloads of the default run")
+    ap.add_argument("--sub", default=None, help="comma-separated sub-workloads instead of C2,C3,C4")
+    ap.add_argument("--strong", action="store_true", help="N>1: split the workload's spp over the ranks (fixed frame) instead of N x spp")
+    ap.add_argument("--device-bvh", nargs="?", const="ploc", default=None, choices=["ploc", "lbvh"],
+                    help="build the BVH on the GPU (rt_bvh_build.hip) instead of on the host: clustering (default) or Morton radix tree")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if world == 0:
+        if args.gpus > 1:
+            spawn_ranks(args.gpus)      # never returns: no GPU call has happened in this process
+        world = 1
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to report one as the other" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import rtiow_loader
+    rt = rtiow_loader.load()
+    dist = None
+    if world > 1 or os.environ.get("RT_BENCH_FORCE_DIST"):   # the env switch rehearses the RCCL calls with one rank on a 1-GPU box
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    n_gpus = dist.get_world_size() if dist is not None else 1      # reported from the initialised group, never from the flag
+
+    B = Bench(args, rt, torch, dist, rank, local_rank, world)
+    head = B.run(args.workload, args.steps, args.warmup, spp=args.spp, width=args.width, cpu=not args.no_cpu and world == 1)
+    subs = {}
+    default_run = args.workload == "C1" and not args.spp and not args.width
+    if world == 1 and not args.no_sub and (default_run or args.sub):
+        names = [s for s in (args.sub.split(",") if args.sub else [w[0] for w in SUB_WORKLOADS]) if s]
+        table = {w[0]: w for w in SUB_WORKLOADS}
+        for nme in names:
+            _, k, wu = table.get(nme, (nme, 3, 1))
+            r = B.run(nme, k, wu)
+            subs[nme] = {"mrays_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "workload": r["config"]["workload"],
+                         "rays_per_step": r["rays_per_step"], "node_visits_per_ray": r["node_visits_per_ray"],
+                         "box_tests_per_ray": r["box_tests_per_ray"], "roofline_frac": r["roofline"]["frac"],
+                         "achieved_tflops": r["roofline"]["achieved"], "kernel_ms": r["roofline"]["kernel_ms"], "traffic": r["roofline"]["traffic"],
+                         "bvh": r["config"]["bvh"], "bvh_nodes": r["config"]["bvh_nodes"], "primitives": r["config"]["primitives"],
+                         "phase_occupancy": r["phase_occupancy"]}
+    if rank == 0:
+        out = {"metric": "Mrays/sec", "value": head["value"], "unit": "Mrays/s", "n_gpus": n_gpus, "steps": head["steps"], "warmup": head["warmup"],
+               "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+        out.update({k: v for k, v in head.items() if k not in out})
+        if subs:
+            out["workloads"] = subs
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    B.gpu.close()
 
 
 if __name__ == "__main__":

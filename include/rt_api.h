@@ -171,12 +171,14 @@ enum rt_mem_location { RT_MEM_HOST = 0, RT_MEM_DEVICE = 1 };
 /* Projection (main.rs:1140-1146); the numbering of the RON config's enum */
 enum rt_projection { RT_PROJ_PERSPECTIVE = 0, RT_PROJ_ORTHOGRAPHIC = 1, RT_PROJ_FISHEYE = 2, RT_PROJ_SPHERICAL_PANORAMIC = 3 };
 
+#define RT_MAX_RAY_DEPTH 65535
 typedef struct rt_render_params {
     uint32_t  struct_size;
     int32_t   image_width, image_height;     /* full frame (main.rs:1160-1161)                 */
     int32_t   samples_per_pixel;             /* spp of the whole frame = sampler samples_in_set */
     int32_t   spp_begin, spp_count;          /* sample range rendered by THIS call             */
-    int32_t   max_ray_depth;                 /* main.rs:1164                                   */
+    int32_t   max_ray_depth;                 /* main.rs:1164; <= RT_MAX_RAY_DEPTH (the reference's i32 is unbounded: beyond
+                                                that rt_render returns RT_E_INVALID); <= 0 renders black, camera.rs:258-262 */
     float     background[3];                 /* main.rs:1172                                   */
     uint32_t  seed;                          /* counter-RNG key; the reference is unseeded     */
     int32_t   tile_x0, tile_y0, tile_x1, tile_y1; /* pixel rectangle, x1/y1 exclusive; 0,0,W,H = all */
@@ -196,7 +198,7 @@ typedef struct rt_stats {
     uint64_t paths;            /* pixel samples started                                 */
     uint64_t rays;             /* closest-hit queries issued by ray_color (camera.rs:264) */
     uint64_t node_visits;      /* BVH nodes fetched                                     */
-    uint64_t box_tests;        /* child boxes tested (2 per node visit)                 */
+    uint64_t box_tests;        /* child boxes tested: the non-empty children (<= 4) of every visited node */
     uint64_t prim_tests[RT_N_PRIM_TYPES]; /* by rt_prim_type, traversal + always-list   */
     uint64_t medium_tests;     /* ConstantMedium::hit evaluations                       */
     uint64_t light_pdf_evals;  /* lights.pdf_value object evaluations                   */

@@ -101,6 +101,18 @@ class HipBackend:
         p.stream = stream_ptr
         self._check(self._L.rt_render(self._h, C.byref(p), out_ptr, None))
 
+    def render_device_stats(self, params, camera, out_ptr, stream_ptr=None, seed=0x5EED, spp_begin=0, spp_count=None, tile=None,
+                            width=None, height=None):
+        """The counting variant into device memory: same paths and image as render_device, returns the rt_stats dict
+        (the call waits for the stream, since it reads the counters back)."""
+        p, W, H = self._params(params, camera, seed, spp_begin, spp_count, tile, width, height)
+        p.out_location = _ffi.RT_MEM_DEVICE
+        p.stream = stream_ptr
+        p.collect_stats = 1
+        st = _ffi.rt_stats()
+        self._check(self._L.rt_render(self._h, C.byref(p), out_ptr, C.byref(st)))
+        return st.as_dict()
+
     def resolve(self, sum_rgba, spp):
         s = np.ascontiguousarray(sum_rgba, np.float32)
         out = np.zeros_like(s)

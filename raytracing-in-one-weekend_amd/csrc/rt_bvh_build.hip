@@ -313,9 +313,13 @@ int build_bvh(hipStream_t stream, const float *d_boxes, uint32_t n, uint32_t lea
     if (n == 0) { out->root_ref = RT_BVH_EMPTY; out->stack_depth = 1; return RT_OK; }
     if (n >= (1u << 28)) { *err = "too many primitives for the device BVH build"; return RT_E_INVALID; }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    RTB_TRY(hipEventCreate(&ev0));
-    RTB_TRY(hipEventCreate(&ev1));
-    RTB_TRY(hipEventRecord(ev0, stream));
+    char *scratch = nullptr;
+    // from here on every error leaves through done(): events and scratch are released whatever was created so far
+    auto done = [&](int rc) { if (scratch) (void)hipFree(scratch); if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); return rc; };
+#define RTB_TRY2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *err = std::string(#call) + ": " + hipGetErrorString(e_); return done(e_ == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP); } } while (0)
+    RTB_TRY2(hipEventCreate(&ev0));
+    RTB_TRY2(hipEventCreate(&ev1));
+    RTB_TRY2(hipEventRecord(ev0, stream));
     const int ni = (int)n - 1;
     const unsigned gn = (n + 255u) / 256u, gi = ((unsigned)(ni > 0 ? ni : 1) + 255u) / 256u;
     // one scratch allocation: keys x2, vals x2, child, parents, ibox, depth, is_node4, index4, max_depth
@@ -325,19 +329,16 @@ int build_bvh(hipStream_t stream, const float *d_boxes, uint32_t n, uint32_t lea
                  o_pi = take(4ull * n), o_pl = take(4ull * n), o_ibox = take(24ull * n), o_arr = take(4ull * n), o_is4 = take(4ull * n),
                  o_ix4 = take(4ull * (n + 1)), o_md = take(256);
     size_t sort_bytes = 0, scan_bytes = 0;
-    RTB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr,
+    RTB_TRY2(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr,
                                                (uint32_t *)nullptr, (int)n, 0, 63, stream));
-    RTB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n + 1, stream));
+    RTB_TRY2(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n + 1, stream));
     const size_t o_tmp = take(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
     const bool ploc = algo != RT_BVH_DEVICE_LBVH;
     // PLOC: two cluster arrays (box + id), the neighbour choice, two flag arrays and their prefix sums
     const size_t o_cb0 = take(ploc ? 24ull * n : 0), o_cb1 = take(ploc ? 24ull * n : 0), o_ci0 = take(ploc ? 4ull * n : 0), o_ci1 = take(ploc ? 4ull * n : 0),
                  o_nn = take(ploc ? 4ull * n : 0), o_va = take(ploc ? 4ull * (n + 1) : 0), o_vp = take(ploc ? 4ull * (n + 1) : 0),
                  o_me = take(ploc ? 4ull * (n + 1) : 0), o_mp = take(ploc ? 4ull * (n + 1) : 0);
-    char *scratch = nullptr;
-    RTB_TRY(hipMalloc((void **)&scratch, off));
-    auto done = [&](int rc) { (void)hipFree(scratch); (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return rc; };
-#define RTB_TRY2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *err = std::string(#call) + ": " + hipGetErrorString(e_); return done(e_ == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP); } } while (0)
+    RTB_TRY2(hipMalloc((void **)&scratch, off));
     auto *k0 = (unsigned long long *)(scratch + o_k0), *k1 = (unsigned long long *)(scratch + o_k1);
     auto *v0 = (uint32_t *)(scratch + o_v0), *v1 = (uint32_t *)(scratch + o_v1);
     auto *child = (int2 *)(scratch + o_child);

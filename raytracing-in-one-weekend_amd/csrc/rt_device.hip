@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "rt_bvh_build.h"
@@ -30,12 +31,14 @@ struct rt_ctx {
     uint32_t stack_depth = 1;
     uint32_t n_bvh_nodes = 0, built_on_device = 0;
     bool bvh_has_general_xform = false;   // some slot under a general Transform sits in a BVH leaf
+    int features = EXT_ALL;               // EXT_* bits the uploaded scene needs (rt_kernels.h); picks the kernel set
     float bvh_build_ms = 0.0f;
     unsigned long long *d_stats = nullptr;  // 64 counters
     hipDeviceProp_t prop{};
     // wavefront workspace (grown on demand, kept until rt_destroy)
     void *wf_pool = nullptr;      size_t wf_pool_entries = 0;   // 2 buffers x entries x 72 B
     float4 *wf_samples = nullptr; size_t wf_samples_entries = 0;
+    bool wf_ready = false;                                      // counters, pinned status words, streams and events below exist
     WfCounters *wf_ctr = nullptr;                               // ring + status words behind it
     StackEntry *wf_ovf = nullptr;  size_t wf_ovf_entries = 0;      // traversal stack overflow (entries beyond the LDS part)
     uint32_t *wf_host_status = nullptr;                         // pinned, per pipeline 2 x 4 words
@@ -107,6 +110,47 @@ size_t env_size(const char *name, size_t dflt, size_t lo, size_t hi) {
     return dflt;
 }
 
+// Kernel sets (rt_kernels.h, EXT): the feature sets the shade / generate / tail kernels are instantiated for.  A scene runs on
+// the smallest set that covers what it contains; the counting variants exist for the full set only (same paths, same bits).
+constexpr int KS_LITE = EXT_NONE;                               // spheres, rectangles, Translate / RotateY, solid + checker: C1, C2
+constexpr int KS_MESH = EXT_TRI | EXT_IMAGE;                    // + triangle meshes and image textures: C4
+constexpr int KS_BOOK2 = EXT_NOISE | EXT_MEDIA | EXT_IMAGE;     // + Perlin noise, media, image textures: C3, C5
+constexpr int KS_FULL = EXT_ALL;                                // + quadrics and general Transforms
+int kernel_set_for(int need) {
+    if ((need & ~KS_LITE) == 0) return KS_LITE;
+    if ((need & ~KS_MESH) == 0) return KS_MESH;
+    if ((need & ~KS_BOOK2) == 0) return KS_BOOK2;
+    return KS_FULL;
+}
+template <bool STATS> struct WfKernels {
+    decltype(&wf_generate_kernel<STATS, KS_FULL>) generate;
+    decltype(&wf_shade_kernel<STATS, KS_FULL>) shade;
+    decltype(&wf_tail_kernel<STATS, KS_FULL>) tail;
+    decltype(&wf_traverse_kernel<STATS, EXT_NONE>) traverse;
+};
+template <bool STATS, int KS> WfKernels<STATS> wf_kernels_of(bool tree_has_xform, bool tree_has_tris) {
+    WfKernels<STATS> k;
+    k.generate = wf_generate_kernel<STATS, KS>;
+    k.shade = wf_shade_kernel<STATS, KS>;
+    k.tail = wf_tail_kernel<STATS, KS>;
+    // the walk's leaf step: spheres and rectangles, + triangles, + slots under a general Transform
+    k.traverse = tree_has_xform ? wf_traverse_kernel<STATS, EXT_XFORM | EXT_TRI> : tree_has_tris ? wf_traverse_kernel<STATS, EXT_TRI> : wf_traverse_kernel<STATS, EXT_NONE>;
+    return k;
+}
+template <bool STATS> WfKernels<STATS> wf_kernels(int features, bool tree_has_xform) {
+    const bool tris = (features & EXT_TRI) != 0;
+    if constexpr (STATS) {
+        return wf_kernels_of<STATS, KS_FULL>(tree_has_xform, tris);
+    } else {
+        switch (kernel_set_for(features)) {
+        case KS_LITE: return wf_kernels_of<STATS, KS_LITE>(tree_has_xform, tris);
+        case KS_MESH: return wf_kernels_of<STATS, KS_MESH>(tree_has_xform, tris);
+        case KS_BOOK2: return wf_kernels_of<STATS, KS_BOOK2>(tree_has_xform, tris);
+        default: return wf_kernels_of<STATS, KS_FULL>(tree_has_xform, tris);
+        }
+    }
+}
+
 constexpr int kMaxPipes = 4;
 constexpr uint32_t kMaxStackDepth = 256;   // traversal stack entries; beyond the LDS part they live in HBM
 constexpr size_t kEntryBytes = 72;   // rt_wavefront.h: 4 float4 + 1 float2 per pool entry
@@ -166,15 +210,36 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         HIP_TRY(ctx, hipMalloc(&ctx->wf_pool, pool * 2 * kEntryBytes * kMaxPipes));
         ctx->wf_pool_entries = pool;
     }
-    if (!ctx->wf_ctr) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->wf_ctr, kMaxPipes * (RT_WF_RING + 1) * sizeof(WfCounters)));   // per pipe: ring + one block for the status words
-        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->wf_host_status, kMaxPipes * 2 * 4 * sizeof(uint32_t), hipHostMallocDefault));
-        for (int q = 0; q < kMaxPipes; ++q) {
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->wf_stream[q], hipStreamNonBlocking));
-            for (hipEvent_t &ev : ctx->wf_event[q]) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_join[q], hipEventDisableTiming));
+    if (!ctx->wf_ready) {   // one-time set-up; on a failure everything made so far is released again, so the next call starts afresh
+        WfCounters *ctr = nullptr;
+        uint32_t *host_status = nullptr;
+        hipStream_t streams[kMaxPipes] = {};
+        hipEvent_t events[kMaxPipes][2] = {}, join[kMaxPipes] = {}, fork = nullptr;
+        hipError_t e = hipMalloc((void **)&ctr, kMaxPipes * (RT_WF_RING + 1) * sizeof(WfCounters));   // per pipe: ring + one block for the status words
+        if (e == hipSuccess) e = hipHostMalloc((void **)&host_status, kMaxPipes * 2 * 4 * sizeof(uint32_t), hipHostMallocDefault);
+        for (int q = 0; q < kMaxPipes && e == hipSuccess; ++q) {
+            e = hipStreamCreateWithFlags(&streams[q], hipStreamNonBlocking);
+            for (hipEvent_t &ev : events[q]) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&join[q], hipEventDisableTiming);
         }
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (ctr) (void)hipFree(ctr);
+            if (host_status) (void)hipHostFree(host_status);
+            for (int q = 0; q < kMaxPipes; ++q) {
+                if (streams[q]) (void)hipStreamDestroy(streams[q]);
+                for (hipEvent_t ev : events[q]) if (ev) (void)hipEventDestroy(ev);
+                if (join[q]) (void)hipEventDestroy(join[q]);
+            }
+            if (fork) (void)hipEventDestroy(fork);
+            return fail(ctx, e == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP, "render workspace set-up failed: %s", hipGetErrorString(e));
+        }
+        ctx->wf_ctr = ctr; ctx->wf_host_status = host_status; ctx->wf_fork = fork;
+        for (int q = 0; q < kMaxPipes; ++q) {
+            ctx->wf_stream[q] = streams[q]; ctx->wf_join[q] = join[q];
+            ctx->wf_event[q][0] = events[q][0]; ctx->wf_event[q][1] = events[q][1];
+        }
+        ctx->wf_ready = true;
     }
     // traversal stack: the first lds_depth entries of every lane in LDS, the (rarely reached) rest in HBM
     const uint32_t lds_want = (uint32_t)env_size("RT_WF_LDS_DEPTH", 20, 1, 64);
@@ -182,7 +247,10 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     const size_t lds = (size_t)lds_depth * 256 * sizeof(StackEntry);
     int per_cu = 0;
     // two instances of the traversal kernel: scenes with a general Transform inside the BVH need the code for it in the leaf step
-    auto *const trav_kernel = ctx->bvh_has_general_xform ? wf_traverse_kernel<STATS, EXT_XFORM> : wf_traverse_kernel<STATS, EXT_NONE>;
+    int features = ctx->features;
+    if (const char *e = getenv("RT_KERNEL_SET")) { if (!strcmp(e, "full")) features = EXT_ALL; }   // A/B: run a scene on the full set
+    const WfKernels<STATS> K = wf_kernels<STATS>(features, ctx->bvh_has_general_xform);
+    auto *const trav_kernel = K.traverse;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel, 256, lds));
     {   // the runtime's answer may assume the 64 KB per-workgroup LDS limit; gfx950 has 160 KB per CU
         hipFuncAttributes fa{};
@@ -203,13 +271,14 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         HIP_TRY(ctx, hipMalloc((void **)&ctx->wf_ovf, ovf_per_pipe * kMaxPipes * sizeof(StackEntry)));
         ctx->wf_ovf_entries = ovf_per_pipe * kMaxPipes;
     }
+    const bool debug = getenv("RT_DEBUG") != nullptr;
     unsigned long long *d_stats = (STATS || kTimers) ? ctx->d_stats : nullptr;
     if (STATS || kTimers) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 64 * sizeof(unsigned long long), stream));
     // the tail kernel (rt_wavefront.h): finishes the last RT_WF_TAIL paths of a batch in one launch; 0 = never.  Default: on for
     // scenes without a BVH walk (measured on MI355X, 32768 against 0: C2 at 16 / 64 / 1000 spp +18 / +8 / +1 %), off with one:
     // there a bounce costs a lone wave as much as an iteration costs the pipeline (C4 at 4 spp +22 %, but C1 at 10 spp, whose last
     // paths rattle inside glass spheres for 40 bounces, -23 %).
-    auto *const tail_kernel = ctx->bvh_has_general_xform ? wf_tail_kernel<STATS, EXT_XFORM> : wf_tail_kernel<STATS, EXT_NONE>;
+    auto *const tail_kernel = K.tail;
     const uint32_t tail_max = (uint32_t)env_size("RT_WF_TAIL", has_bvh ? 0 : 32768, 0, 1u << 20);
     unsigned tail_nb = (tail_max + 4095u) / 4096u;                       // one lane per path: 64 shards x tail_nb waves
     if (tail_nb > trav_blocks / 16u) tail_nb = trav_blocks / 16u;        // its lanes share the pipeline's stack overflow area
@@ -224,7 +293,9 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         StackEntry *ovf;
         WfArgs w;
         uint32_t it, groups;
-        unsigned pool_blocks;
+        unsigned chunks;          // shade / generate grid: chunks of 256 entries per shard (x), 64 shards (y)
+        unsigned trav_blocks;     // traverse grid (a multiple of the 64 shards)
+        bool items_out;           // the host has seen a status with every item handed out: the pool only shrinks from there
         bool drained;
     } pipe[kMaxPipes];
     for (int q = 0; q < n_pipes; ++q) {
@@ -260,10 +331,12 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             w.pool = (uint32_t)(items_up < ctx->wf_pool_entries ? items_up : ctx->wf_pool_entries);
             if (w.pool > pool_want) w.pool = (uint32_t)pool_want;
             w.cap = w.pool / RT_WF_SHARDS;
-            P.pool_blocks = w.pool / 256u;
+            P.chunks = w.cap / 256u;
+            P.items_out = false;
+            P.trav_blocks = trav_blocks;
             HIP_TRY(ctx, hipMemsetAsync(P.ctr, 0, (RT_WF_RING + 1) * sizeof(WfCounters), P.s));
             P.it = 0; P.groups = 0; P.drained = false;
-            hipLaunchKernelGGL(wf_generate_kernel<STATS>, dim3(P.pool_blocks), dim3(256), 0, P.s, ctx->sc, w, P.Q[1], P.ctr, P.it,
+            hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, w, P.Q[1], P.ctr, P.it,
                                ctx->wf_samples, P.d_status, d_stats, d_rays);
         }
         for (int live = n_pipes; live > 0;) {
@@ -274,17 +347,27 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                 if (group >= 2) {   // look at the status copied after group - 2
                     HIP_TRY(ctx, hipEventSynchronize(ctx->wf_event[q][group & 1]));
                     const uint32_t *hs = P.h_status + 4 * (group & 1);
+                    if (debug) fprintf(stderr, "[rt] pipe %d after iteration %u: %u paths live, %u of %u items out\n", q, hs[2], hs[0], hs[1], P.w.n_items);
                     if (hs[0] == 0u && hs[1] == P.w.n_items) { P.drained = true; --live; continue; }
                     if (p->cancel && *p->cancel) { (void)hipDeviceSynchronize(); return fail(ctx, RT_E_CANCELLED, "cancelled"); }
+                    if (hs[3] != 0xffffffffu) {   // every item is out and the largest shard held hs[3] paths: the pool only shrinks from there,
+                        P.items_out = true;       // so the grids shrink with it (an empty iteration then costs a few microseconds, not 3 x 15)
+                        const unsigned need = (hs[3] + 255u) / 256u;
+                        P.chunks = need < 1u ? 1u : (need < P.w.cap / 256u ? need : P.w.cap / 256u);
+                        const unsigned tb = P.chunks * RT_WF_SHARDS;
+                        P.trav_blocks = tb < trav_blocks ? tb : trav_blocks;
+                    }
                 }
-                for (int k = 0; k < 8; ++k) {
+                // groups of 8 iterations while items are handed out; 4 in the tail, where what is enqueued after the pool has
+                // drained (the host learns of it a group late) is pure waste
+                for (int k = 0, gsize = P.items_out ? 4 : 8; k < gsize; ++k) {
                     const uint32_t it = ++P.it;
                     const PathQ &cur = P.Q[it & 1], &nxt = P.Q[(it + 1) & 1];
-                    if (has_bvh) hipLaunchKernelGGL(trav_kernel, dim3(trav_blocks), dim3(256), lds, P.s, ctx->sc, cur, P.ctr, it, P.w.cap,
+                    if (has_bvh) hipLaunchKernelGGL(trav_kernel, dim3(P.trav_blocks), dim3(256), lds, P.s, ctx->sc, cur, P.ctr, it, P.w.cap,
                                                     lds_depth, P.ovf, d_stats);
-                    hipLaunchKernelGGL(wf_shade_kernel<STATS>, dim3(P.pool_blocks), dim3(256), 0, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
+                    hipLaunchKernelGGL(K.shade, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
                                        ctx->wf_samples, d_stats, d_rays);
-                    hipLaunchKernelGGL(wf_generate_kernel<STATS>, dim3(P.pool_blocks), dim3(256), 0, P.s, ctx->sc, P.w, nxt, P.ctr, it,
+                    hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, nxt, P.ctr, it,
                                        ctx->wf_samples, P.d_status, d_stats, d_rays);
                     if (tail_max && (k & 3) == 3)
                         hipLaunchKernelGGL(tail_kernel, dim3(RT_WF_SHARDS * tail_nb), dim3(64), tail_lds, P.s, ctx->sc, P.w, nxt, P.ctr, it + 1u,
@@ -406,7 +489,31 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         for (int32_t r : refs)
             if (!ref_ok(r)) return fail(ctx, RT_E_INVALID, "bvh node %u has a child out of range", i);
     }
+    // The walk pushes without a bound check and its persistent waves only end when every stack has drained: a node reachable
+    // twice (a cycle or a shared subtree) or a stack_depth below what the tree needs would be a GPU fault or a hang.  Walk the
+    // tree from the root: every inner node is reached at most once, and a visit at inner depth d (root = 1) can leave
+    // 3 (d - 1) siblings on the stack and push 3 more, so the stack must hold 3 d entries (the host builder declares 3 d + 2).
+    if (!device_build && s->bvh_root_ref != RT_BVH_EMPTY && s->bvh_root_ref >= 0) {
+        std::vector<uint8_t> seen(s->n_bvh_nodes, 0);
+        std::vector<std::pair<int32_t, uint32_t>> todo;   // (node, inner depth)
+        todo.push_back({s->bvh_root_ref, 1u});
+        uint32_t max_depth = 0;
+        while (!todo.empty()) {
+            const auto [node, depth] = todo.back();
+            todo.pop_back();
+            if (seen[(size_t)node]) return fail(ctx, RT_E_INVALID, "bvh node %d is reachable twice (cycle or shared subtree)", node);
+            seen[(size_t)node] = 1;
+            if (depth > max_depth) max_depth = depth;
+            int32_t refs[4];
+            memcpy(refs, &s->bvh_nodes[(size_t)node * RT_NODE_FLOATS + 12], 16);
+            for (int32_t r : refs)
+                if (r >= 0 && r != RT_BVH_EMPTY) todo.push_back({r, depth + 1u});
+        }
+        if (3u * max_depth > s->bvh_stack_depth)
+            return fail(ctx, RT_E_INVALID, "bvh_stack_depth %u is too small for this tree: %u inner levels need %u entries", s->bvh_stack_depth, max_depth, 3u * max_depth);
+    }
     bool tris = false, general_in_bvh = false;
+    int need = s->n_media ? EXT_MEDIA : EXT_NONE;     // EXT_* features the scene needs (kernel set, rt_kernels.h)
     for (uint32_t i = 0; i < s->n_slots; ++i) {
         int32_t w4, mat;
         memcpy(&w4, &s->slots[i * RT_SLOT_FLOATS + 4], 4);
@@ -426,6 +533,9 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         // quadrics may accept hits below t_min (cone.rs:61-65): the traversal kernels do not carry their code
         if (type >= RT_PRIM_CYLINDER && !in_always) return fail(ctx, RT_E_INVALID, "slot %u: quadrics must be in the always-list", i);
         general_in_bvh |= general && !in_always;
+        if (general) need |= EXT_XFORM;
+        if (type >= RT_PRIM_CYLINDER) need |= EXT_QUADRICS;
+        if (type == RT_PRIM_TRIANGLE) need |= EXT_TRI;
         if (mat < 0 || (uint32_t)mat >= s->n_materials) return fail(ctx, RT_E_INVALID, "slot %u: material out of range", i);
         tris |= type == RT_PRIM_TRIANGLE;
     }
@@ -448,6 +558,8 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         if (w[0] < 0 || w[0] > RTG_TEX_IMAGE) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "texture %u: type %d", i, w[0]);
         if (w[0] == RTG_TEX_CHECKER && (w[4] < 0 || w[5] < 0 || (uint32_t)w[4] >= s->n_textures || (uint32_t)w[5] >= s->n_textures))
             return fail(ctx, RT_E_INVALID, "texture %u: checker child out of range", i);
+        if (w[0] == RTG_TEX_NOISE) need |= EXT_NOISE;
+        if (w[0] == RTG_TEX_IMAGE) need |= EXT_IMAGE;
         if (w[0] == RTG_TEX_NOISE && (w[4] < 0 || (uint32_t)w[4] >= s->n_perlin)) return fail(ctx, RT_E_INVALID, "texture %u: perlin table out of range", i);
         if (w[0] == RTG_TEX_IMAGE && w[4] >= 0 && (w[5] <= 0 || w[7] <= 0 || ((uint64_t)w[4] + (uint64_t)w[5] * (uint64_t)w[7]) * 4 > s->n_texel_bytes))
             return fail(ctx, RT_E_INVALID, "texture %u: image outside the texel atlas", i);
@@ -516,6 +628,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     ctx->n_bvh_nodes = s->n_bvh_nodes;
     ctx->built_on_device = 0;
     ctx->bvh_has_general_xform = general_in_bvh;
+    ctx->features = need;
     ctx->bvh_build_ms = 0.0f;
     if (device_build) {
         // Morton order decides where a slot goes: build over the boxes, then gather slots and triangle attributes into
@@ -639,6 +752,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
     if (p->samples_per_pixel != (int32_t)ctx->sc.spp) return fail(ctx, RT_E_INVALID, "samples_per_pixel %d does not match the sampler table (%u)", p->samples_per_pixel, ctx->sc.spp);
     if (p->spp_begin < 0 || p->spp_count < 0 || p->spp_begin + p->spp_count > p->samples_per_pixel) return fail(ctx, RT_E_INVALID, "sample range outside [0, spp)");
     if (p->collect_stats && !stats) return fail(ctx, RT_E_INVALID, "collect_stats without a stats struct");
+    if (p->max_ray_depth > RT_MAX_RAY_DEPTH) return fail(ctx, RT_E_INVALID, "max_ray_depth %d: at most %d (a path's remaining depth travels in 16 bits)", p->max_ray_depth, RT_MAX_RAY_DEPTH);
     if (p->projection < RT_PROJ_PERSPECTIVE || p->projection > RT_PROJ_SPHERICAL_PANORAMIC) return fail(ctx, RT_E_INVALID, "unknown projection %d", p->projection);
     int x0 = p->tile_x0 < 0 ? 0 : p->tile_x0, y0 = p->tile_y0 < 0 ? 0 : p->tile_y0;
     int x1 = p->tile_x1 > p->image_width ? p->image_width : p->tile_x1, y1 = p->tile_y1 > p->image_height ? p->image_height : p->tile_y1;
@@ -704,7 +818,6 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
     if (p->collect_stats) {
         memset(stats, 0, sizeof *stats);
         stats->paths = h_stats[0]; stats->rays = h_stats[1]; stats->node_visits = h_stats[2];
-        stats->box_tests = 2 * h_stats[2];
         constexpr int P = RT_N_PRIM_TYPES;   // order: flush_counters (rt_wavefront.h)
         for (int i = 0; i < P; ++i) stats->prim_tests[i] = h_stats[3 + i];
         stats->medium_tests = h_stats[3 + P]; stats->light_pdf_evals = h_stats[4 + P];
@@ -712,6 +825,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
         for (int i = 0; i < 4; ++i) stats->tex_evals[i] = h_stats[10 + P + i];
         stats->accepted_hits = h_stats[14 + P];
         for (int i = 0; i < 5; ++i) { stats->phase_lanes[i] = h_stats[15 + P + i]; stats->phase_slots[i] = h_stats[20 + P + i]; }
+        stats->box_tests = h_stats[25 + P];
     }
     return RT_OK;
 }

@@ -1,20 +1,20 @@
-// rt_kernels.h — device code of the path tracer (gfx950).
+// rt_kernels.h — device functions of the path tracer (gfx950): primitive tests, the BVH walk, textures, pdfs,
+// one bounce of ray_color, camera rays, and the small stand-alone kernels (parity hook, resolve).
 //
-// One lane carries one camera path at a time and regenerates a new sample of ITS pixel as
-// soon as the path ends, so a wave stays full until its 8x8 pixel tile has no samples left
-// (persistent lanes instead of the reference's per-pixel fold, camera.rs:186-251).
-// `ray_color` (camera.rs:253-309) is evaluated front-to-back: the recursion
-//     L = e0 + w0 * (e1 + w1 * (...))      is accumulated as      L += T*e_k ; T *= w_k.
-// Everything that decides WHERE a path goes (hit tests, scatter directions, pdfs, random
-// draws) follows the reference operation by operation — single IEEE f32 operations, no
-// contraction — so a path is bit-identical to the CPU oracle's; only the radiance products
-// are associated differently (<= a few ulp per bounce).
+// The render itself is the streaming pipeline of rt_wavefront.h (generate / traverse / shade / fold over a pool of
+// in-flight paths); this file holds what those kernels call.  `ray_color` (camera.rs:253-309) is evaluated
+// front-to-back: the recursion  L = e0 + w0 * (e1 + w1 * (...))  becomes a running throughput, and because every
+// reference material either scatters with emitted() = black or emits and ends the path, radiance is only ever added
+// by the bounce that ends a path.  Everything that decides WHERE a path goes (hit tests, scatter directions, pdfs,
+// random draws) follows the reference operation by operation — single IEEE f32 operations, no contraction — so a
+// path is bit-identical to the CPU oracle's; only the radiance products are associated differently.
 //
-// The closest-hit search is the part that is NOT the reference's algorithm: a 2-wide BVH over
-// ALL leaf primitives (64-byte nodes holding both child boxes, 64-byte primitive slots),
-// traversed with a per-lane stack in LDS.  It reproduces HittableList::hit semantics
-// (hittable_list.rs:39-50): closest t, and on an exact tie the object later in the list —
-// the larger primitive id — wins.
+// The closest-hit search is the part that is NOT the reference's algorithm: a 4-wide BVH over ALL leaf primitives
+// (64-byte nodes holding the four child boxes quantised to 8 bits on the node's own grid, 64-byte primitive slots),
+// walked with a per-lane stack of node refs in LDS (overflow in HBM).  It reproduces HittableList::hit semantics
+// (hittable_list.rs:39-50): closest t, and on an exact tie the object later in the list — the larger primitive id —
+// wins.  Tests that can be rejected without the reference's exact arithmetic are rejected by conservative
+// pre-tests (boxes; the always-list's reciprocal-estimate filter); whatever is accepted went through the exact test.
 #ifndef RT_KERNELS_H
 #define RT_KERNELS_H
 
@@ -101,10 +101,11 @@ struct DScene {
 };
 
 #define RT_N_REGIONS 24
-#define RT_STAT_WORDS (25 + RT_N_PRIM_TYPES)   // counters of one render (flush_counters); the region timers follow
+#define RT_STAT_WORDS (26 + RT_N_PRIM_TYPES)   // counters of one render (flush_counters); the region timers follow
 struct Counters {  // only live in the STATS instantiation
     uint32_t rays, node_visits, prim_tests[RT_N_PRIM_TYPES], medium_tests, light_pdf_evals, shades[5], tex_evals[4], accepted;
     uint32_t phase_lanes[5], phase_slots[5];
+    uint32_t box_tests;              // child boxes tested by node4_visit (the non-empty children of every visited node)
     uint32_t region[RT_N_REGIONS];   // cycles a wave spent in a code region (counted on its first active lane)
 };
 // Region timers (development builds with -DRT_REGION_TIMERS=1 only; they time the product kernels, not the
@@ -147,10 +148,17 @@ RT_DEV float mat_row(float4 m, V3 v, float w) { return m.x * v.x + m.y * v.y + m
 RT_DEV V3 mat_apply(const float4 *m, V3 v, float w) { return v3(mat_row(m[0], v, w), mat_row(m[1], v, w), mat_row(m[2], v, w)); }
 
 // Ray into the frame of a wrapped primitive: Translate (transform.rs:34) then RotateY (:117-126), or a general
-// Transform (transform.rs:190 + math/src/ray.rs:42-54).  EXT selects what is compiled in: bit 0 the general Transform,
-// bit 1 the quadrics.  The traversal kernel exists without either (scenes with no general Transform in the BVH keep the
-// smaller code) and with the Transform; quadrics are never reached through the BVH (rt_api.h).
-enum { EXT_NONE = 0, EXT_XFORM = 1, EXT_QUADRICS = 2, EXT_ALL = 3 };
+// Transform (transform.rs:190 + math/src/ray.rs:42-54).
+//
+// EXT = what a kernel instance has code for (a bit mask).  The shade / generate / tail kernels inline every primitive,
+// material and texture the backend covers: 90 KB of code and 90-130 VGPRs for a Cornell box that needs a sixth of it, with an
+// instruction cache of 64 KB per two CUs.  So they are instantiated for a few feature sets and rt_scene_upload picks the
+// smallest one that covers the scene (rt_device.hip: kernel_set).  Code for a feature that is compiled out is never
+// reached by a scene without it, so which instance runs changes no bit.  Quadrics are never reached through the BVH
+// (rt_api.h); the traversal kernel therefore only distinguishes "general Transform inside the tree" or not.
+enum { EXT_NONE = 0, EXT_XFORM = 1 /* general Transform */, EXT_QUADRICS = 2, EXT_NOISE = 4 /* Perlin noise texture */,
+       EXT_MEDIA = 8 /* ConstantMedium + Isotropic */, EXT_TRI = 16 /* triangle meshes */, EXT_IMAGE = 32 /* image textures (u, v) */,
+       EXT_ALL = 63 };
 template <int EXT = EXT_ALL>
 RT_DEV Ray to_object_rec(const DScene &sc, float4 a, float4 b, const Ray &r) {
     int flags = f2i(a.x);
@@ -397,7 +405,7 @@ RT_DEV V3 quadric_record(int type, const SlotRec &s, const QuadHit &h, float *u,
 // EXT: see to_object_rec.
 template <bool STATS, int EXT = EXT_ALL>
 RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, const Ray &r_world, float t_min, float t_max, float *t_out,
-                         int32_t *id_out, Counters &cnt, const Ray *r_object = nullptr /* the ray already in the slot's frame */) {
+                         int32_t *id_out, Counters &cnt, bool have_object, const Ray r_object /* the ray already in the slot's frame, if have_object */) {
     const float4 q0 = s.q0, meta = s.meta;
     int w4 = f2i(meta.x);
     int type = w4 & 15;
@@ -405,7 +413,7 @@ RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, cons
     *id_out = f2i(meta.z);
     if (STATS) cnt.prim_tests[type] += 1;
     Ray r = r_world;
-    if (r_object) r = *r_object;
+    if (have_object) r = r_object;
     else if (xf >= 0) r = type_has_inline_xform(type) ? to_object_rec<EXT>(sc, s.q2, s.q3, r_world) : to_object<EXT>(sc, xf, r_world);
     if ((EXT & EXT_QUADRICS) && type >= RT_PRIM_CYLINDER) {
         QuadHit qh;
@@ -423,6 +431,7 @@ RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, cons
     case RT_PRIM_XY_RECT: case RT_PRIM_XZ_RECT: case RT_PRIM_YZ_RECT:
         return rect_test(type, q0, meta.w, r, t_min, t_max, t_out, &a, &b);
     default: {
+        if (!(EXT & EXT_TRI)) return false;
         TriHit th;
         if (!tri_test(sc, slot, q0, meta.w, s.q2, r, t_min, t_max, &th)) return false;
         *t_out = th.t;
@@ -433,7 +442,7 @@ RT_DEV bool slot_hit_rec(const DScene &sc, uint32_t slot, const SlotRec &s, cons
 template <bool STATS, int EXT = EXT_ALL>
 RT_DEV bool slot_hit(const DScene &sc, uint32_t slot, const Ray &r_world, float t_min, float t_max, float *t_out, int32_t *id_out,
                      Counters &cnt) {
-    return slot_hit_rec<STATS, EXT>(sc, slot, load_slot(sc, slot), r_world, t_min, t_max, t_out, id_out, cnt);
+    return slot_hit_rec<STATS, EXT>(sc, slot, load_slot(sc, slot), r_world, t_min, t_max, t_out, id_out, cnt, false, r_world);
 }
 
 RT_DEV void sphere_uv(V3 p, float *u, float *v) {  // sphere.rs:25-41
@@ -446,6 +455,7 @@ RT_DEV void sphere_uv(V3 p, float *u, float *v) {  // sphere.rs:25-41
 // Full HitRecord of a slot for a known t: the same arithmetic as the leaf's hit() followed by
 // the wrappers on the way out (RotateY transform.rs:128-143, Translate :35-44, Transform :192-203, FlipFace).
 // t_min / t_max: the bounds the accepted test ran with (a quadric repeats its test to know which root it took).
+template <int EXT = EXT_ALL>
 RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, float t, bool want_uv, float t_min, float t_max) {
     const SlotRec s = load_slot(sc, slot);
     float4 q0 = s.q0, meta = s.meta;
@@ -457,13 +467,13 @@ RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, floa
         if (type_has_inline_xform(type)) { xa = s.q2; xb = s.q3; }
         else { xa = sc.xforms[2 * xf]; xb = sc.xforms[2 * xf + 1]; }
     }
-    Ray r = xf >= 0 ? to_object_rec(sc, xa, xb, r_world) : r_world;
+    Ray r = xf >= 0 ? to_object_rec<EXT>(sc, xa, xb, r_world) : r_world;
     Rec rec;
     rec.t = t;
     rec.material = f2i(meta.y);
     rec.u = 0.0f; rec.v = 0.0f;
     V3 p = r.at(t), n;
-    if (type >= RT_PRIM_CYLINDER) {
+    if ((EXT & EXT_QUADRICS) && type >= RT_PRIM_CYLINDER) {
         QuadHit qh;
         quadric_test(type, s, r, t_min, t_max, &qh);   // same arithmetic as the accepted test
         p = qh.p;
@@ -474,7 +484,7 @@ RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, floa
         V3 c = v3(q0.x, q0.y, q0.z);
         if (type == RT_PRIM_MOVING_SPHERE) c = moving_center(q0, meta.w, s.q2, r.time);
         n = (p - c) / q0.w;
-        if (want_uv) sphere_uv(n, &rec.u, &rec.v);
+        if ((EXT & EXT_IMAGE) && want_uv) sphere_uv(n, &rec.u, &rec.v);
         break;
     }
     case RT_PRIM_XY_RECT: case RT_PRIM_XZ_RECT: case RT_PRIM_YZ_RECT: {
@@ -489,6 +499,7 @@ RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, floa
         break;
     }
     default: {
+        if (!(EXT & EXT_TRI)) { n = v3(0.0f, 0.0f, 0.0f); break; }
         TriHit th;
         tri_test(sc, slot, q0, meta.w, s.q2, r, -RT_F32_MAX, RT_F32_MAX, &th);  // same arithmetic as the accepted test
         n = th.n;
@@ -502,7 +513,7 @@ RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, floa
     V3 nn = front ? n : -n;
     if (xf >= 0) {
         int flags = f2i(xa.x);
-        if (flags & 4) {   // transform.rs:195-201: p and normal to world space, front_face / t / u / v kept
+        if ((EXT & EXT_XFORM) && (flags & 4)) {   // transform.rs:195-201: p and normal to world space, front_face / t / u / v kept
             const float4 *m = sc.matrices + 9 * (size_t)f2i(xa.y);
             p = mat_apply(m + 3, p, 1.0f);
             nn = normalize(mat_apply(m + 6, nn, 0.0f));
@@ -573,7 +584,8 @@ RT_DEV int32_t pop_ref(const Stack &st, uint32_t &sp) {
 // nearest hit child is returned, the other hit children are pushed farthest first (so the nearer one is popped
 // first); with no hit the next stack entry is returned.  The order only decides how soon best_t shrinks: the
 // closest hit and its tie-break do not depend on it.
-RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t_min, float best_t, const Stack &stack, uint32_t &sp) {
+template <bool STATS>
+RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t_min, float best_t, const Stack &stack, uint32_t &sp, Counters &cnt) {
     const float4 *n = sc.nodes + 4 * (size_t)ref;
     const float4 n0 = n[0], n1 = n[1], n2 = n[2], rf = n[3];
     // plane = origin + scale * q, so its ray parameter (plane - o) * inv is q * (scale * inv) + (origin * inv - o * inv)
@@ -594,6 +606,7 @@ RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t
         const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
         const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), best_t));
         const bool hit = tn <= tf * 1.0000004f && refs[c] != RT_BVH_EMPTY;
+        if (STATS && refs[c] != RT_BVH_EMPTY) cnt.box_tests += 1;
         key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xffffffffu;
     }
 #define RT_CSWAP(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
@@ -628,7 +641,7 @@ RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_
     for (;;) {
         while (ref >= 0 && ref != RT_BVH_EMPTY) {
             if (STATS) cnt.node_visits += 1;
-            ref = node4_visit(sc, ref, inv, oi, t_min, best.t, stack, sp);
+            ref = node4_visit<STATS>(sc, ref, inv, oi, t_min, best.t, stack, sp, cnt);
         }
         if (ref == RT_BVH_EMPTY) return;
         uint32_t code = (uint32_t)~ref;
@@ -636,7 +649,7 @@ RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_
         for (uint32_t i = 0; i < count; ++i) {
             float t;
             int32_t id;
-            if (slot_hit<STATS, EXT_XFORM>(sc, first + i, r, t_min, best.t, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)(first + i));
+            if (slot_hit<STATS, EXT_XFORM | EXT_TRI>(sc, first + i, r, t_min, best.t, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)(first + i));
         }
         ref = pop_ref(stack, sp);
     }
@@ -666,6 +679,161 @@ RT_DEV bool medium_hit(const DScene &sc, uint32_t m, const Ray &r, float t_min, 
 
 RT_DEV bool finite_f(float x) { return fabsf(x) < INFINITY; }
 
+/* ------------------------------------------------------------------ the always-list */
+
+// The always-list is the reference's flat `world` scan for the slots the BVH does not hold (every leaf of a scene of up to
+// 24 leaves: the Cornell box, Blocks; quadrics anywhere): every slot is tested against every ray with the SAME (t_min, t_max)
+// (hittable_list.rs:39-50).  Most of those slots are rectangles, and their exact test is one correctly rounded division per
+// rectangle and ray (rectangles.rs:22) although a ray inside a closed box can hit one or two of them.  So the scan runs in
+// two phases that change no bit of the result:
+//   1. a conservative pre-test per rectangle (wave-uniform slot index, slot data in scalar registers): the ray parameter
+//      from a reciprocal ESTIMATE (v_rcp_f32, 1 ulp) and the hit point from it, compared against the bounds widened by an
+//      error margin.  A slot it rejects cannot be accepted by the exact test (proof below).  Lanes whose ray could produce
+//      an inf or NaN anywhere in the exact test (a direction component outside [2^-40, 2^40], an origin beyond 2^40) keep
+//      every rectangle as a candidate.
+//   2. each lane runs the UNCHANGED exact test on its own candidates only (per-lane slot index), so the wave iterates
+//      max-over-lanes candidates (2-3 in a closed box) instead of all rectangles; slots of other kinds (spheres, quadrics,
+//      ...) go through the exact test as before, wave-uniform.
+// The fold (`consider`) does not depend on the order candidates arrive in.
+//
+// Error bound of the pre-test (u = 2^-24, E = 2^-19; all quantities finite and normal by the range check, denormal results
+// are covered by the absolute slack 1e-30): exact t = fl(n / d) and estimate t' = fl(n * rcp(d)) with the same n = fl(k - o)
+// differ by |t' - t| <= |t| (2^-23 + 2u) < |t| 2^-21.  Exact a = fl(o_A + fl(t d_A)), estimate a' = fl(fl(t' d_A) + o_A):
+// |a' - a| <= |t d_A| (2^-21 + 4u) + 2u |o_A| < (|fl(t' d_A)| + |o_A|) 2^-20 = eps / 2.  The pre-test rejects on
+// a' + eps < a0 (resp. a' - eps > a1), i.e. only if a < a0 (a > a1), which the exact test rejects too; the rounding of
+// a' +- eps is below eps / 16.  t' (1 + E) + 1e-30 < t_min implies t < t_min likewise (t and t' have the same sign).
+#define RT_FILTER_E 1.9073486328125e-06f          /* 2^-19 */
+#define RT_FILTER_RANGE 1.099511627776e+12f       /* 2^40 */
+
+RT_DEV bool filter_range_ok(const Ray &r) {       // false -> this lane skips the pre-test (every rectangle is a candidate)
+    const float lo = 1.0f / RT_FILTER_RANGE, hi = RT_FILTER_RANGE;
+    const float ax = fabsf(r.d.x), ay = fabsf(r.d.y), az = fabsf(r.d.z);
+    return ax >= lo && ay >= lo && az >= lo && ax <= hi && ay <= hi && az <= hi &&
+           fabsf(r.o.x) <= hi && fabsf(r.o.y) <= hi && fabsf(r.o.z) <= hi;
+}
+
+template <int AX, int A, int B>
+RT_DEV bool rect_maybe_axes(float4 q0, float k, const Ray &r, V3 rcp, float t_min, float t_max) {
+    const float E = RT_FILTER_E;
+    const float t = (k - comp(r.o, AX)) * comp(rcp, AX);
+    const float pa = t * comp(r.d, A), pb = t * comp(r.d, B);
+    const float a = pa + comp(r.o, A), b = pb + comp(r.o, B);
+    const float ea = __builtin_fmaf(fabsf(pa) + fabsf(comp(r.o, A)), E, 1.0e-30f);
+    const float eb = __builtin_fmaf(fabsf(pb) + fabsf(comp(r.o, B)), E, 1.0e-30f);
+    const float et = __builtin_fmaf(fabsf(t), E, 1.0e-30f);
+    const bool out = t + et < t_min || t - et > t_max || a + ea < q0.x || a - ea > q0.y || b + eb < q0.z || b - eb > q0.w;
+    return !out;
+}
+RT_DEV bool rect_maybe(int type, float4 q0, float k, const Ray &r, V3 rcp, float t_min, float t_max) {   // type is wave-uniform here
+    if (!(fabsf(k) <= RT_FILTER_RANGE)) return true;   // a plane that far out: no pre-test
+    if (type == RT_PRIM_XY_RECT) return rect_maybe_axes<2, 0, 1>(q0, k, r, rcp, t_min, t_max);
+    if (type == RT_PRIM_XZ_RECT) return rect_maybe_axes<1, 0, 2>(q0, k, r, rcp, t_min, t_max);
+    return rect_maybe_axes<0, 1, 2>(q0, k, r, rcp, t_min, t_max);
+}
+
+// rect_test_axes with the axes picked per lane: the same operations on the same operands, so the same bits.
+RT_DEV bool rect_test_lane(int type, float4 q0, float k, const Ray &r, float t_min, float t_max, float *t_out) {
+    const bool xy = type == RT_PRIM_XY_RECT, yz = type == RT_PRIM_YZ_RECT;
+    // (the components go through an empty asm first: left alone, the optimiser turns "select between fields of a Ray" into a
+    // dynamically indexed load from a Ray it then has to keep in memory — 28 bytes of LDS per thread)
+    float ox = r.o.x, oy = r.o.y, oz = r.o.z, dx = r.d.x, dy = r.d.y, dz = r.d.z;
+    asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz), "+v"(dx), "+v"(dy), "+v"(dz));
+    const float o_ax = xy ? oz : (yz ? ox : oy), d_ax = xy ? dz : (yz ? dx : dy);
+    const float o_a = yz ? oy : ox, d_a = yz ? dy : dx;
+    const float o_b = xy ? oy : oz, d_b = xy ? dy : dz;
+    const float t = (k - o_ax) / d_ax;
+    if (t < t_min || t > t_max) return false;
+    const float a = o_a + t * d_a;
+    const float b = o_b + t * d_b;
+    if (a < q0.x || a > q0.y || b < q0.z || b > q0.w) return false;
+    *t_out = t;
+    return true;
+}
+
+#ifndef RT_ALWAYS_FILTER
+#define RT_ALWAYS_FILTER 0      // 1 = two-phase scan (conservative pre-test + per-lane exact test); measured SLOWER on MI355X, see DESIGN.md §3
+#endif
+template <bool STATS, int EXT = EXT_ALL>
+RT_DEV void always_scan(const DScene &sc, const Ray &r, float t_min, float t_max, int32_t floor_id, Hit &best, Counters &cnt) {
+#if !RT_ALWAYS_FILTER
+    if (sc.always_count) {   // the slot index is wave-uniform: fetch slot i+1 while slot i is tested
+        SlotRec nx = load_slot(sc, sc.always_begin);
+        int frame_xf = -1;   // consecutive slots under one transform (the six sides of a block) share the transformed ray
+        Ray r_frame = r;
+        for (uint32_t i = 0; i < sc.always_count; ++i) {
+            const SlotRec cu = nx;
+            const uint32_t s = sc.always_begin + i;
+            if (i + 1 < sc.always_count) nx = load_slot(sc, s + 1);
+            const int w4 = f2i(cu.meta.x), xf = (w4 >> 8) - 1;   // wave-uniform
+            if (xf != frame_xf) {
+                frame_xf = xf;
+                r_frame = xf < 0 ? r : (type_has_inline_xform(w4 & 15) ? to_object_rec<EXT>(sc, cu.q2, cu.q3, r) : to_object<EXT>(sc, xf, r));
+            }
+            float t; int32_t id;
+            if (slot_hit_rec<STATS, EXT>(sc, s, cu, r, t_min, t_max, &t, &id, cnt, true, r_frame) && id > floor_id) consider(best, t, id, (int32_t)s);
+        }
+    }
+    return;
+#endif
+    for (uint32_t c0 = 0; c0 < sc.always_count; c0 += 32u) {      // 32 slots at a time: one mask word
+        const uint32_t cn = sc.always_count - c0 < 32u ? sc.always_count - c0 : 32u, s0 = sc.always_begin + c0;
+        uint32_t cand = 0u;      // per lane: rectangles the exact test may accept
+        uint32_t rects = 0u;     // wave-uniform: which of the cn slots are rectangles
+        bool unfiltered = false; // per lane: the ray is outside the pre-test's range in some frame
+        {
+            SlotRec nx = load_slot(sc, s0);
+            int frame_xf = -2;   // consecutive slots under one transform (the six sides of a block) share the transformed ray
+            Ray rf = r;
+            V3 rcp = v3(0.0f, 0.0f, 0.0f);
+            for (uint32_t i = 0; i < cn; ++i) {      // phase 1; the slot index is wave-uniform: fetch slot i+1 while slot i is tested
+                const SlotRec cu = nx;
+                if (i + 1 < cn) nx = load_slot(sc, s0 + i + 1);
+                const int w4 = f2i(cu.meta.x), type = w4 & 15, xf = (w4 >> 8) - 1;
+                // rectangles, plain or under Translate / RotateY; one under a general Transform stays with the "other kinds"
+                // (its matrices would have to sit in vector registers per lane: 36 of them)
+                if (type < RT_PRIM_XY_RECT || type > RT_PRIM_YZ_RECT || (xf >= 0 && (f2i(cu.q2.x) & 4))) continue;
+                rects |= 1u << i;
+                if (STATS) cnt.prim_tests[type] += 1;
+                if (xf != frame_xf) {
+                    frame_xf = xf;
+                    rf = xf < 0 ? r : to_object_rec<EXT_NONE>(sc, cu.q2, cu.q3, r);
+                    rcp = v3(__builtin_amdgcn_rcpf(rf.d.x), __builtin_amdgcn_rcpf(rf.d.y), __builtin_amdgcn_rcpf(rf.d.z));
+                    unfiltered = unfiltered || !filter_range_ok(rf);
+                }
+                if (rect_maybe(type, cu.q0, cu.meta.w, rf, rcp, t_min, t_max)) cand |= 1u << i;
+            }
+        }
+        if (unfiltered) cand = rects;
+        while (cand != 0u) {     // phase 2, rectangles: every lane takes its own next candidate
+            const uint32_t i = (uint32_t)__builtin_ctz(cand), s = s0 + i;
+            cand &= cand - 1u;
+            const float4 *ps = sc.slots + 4 * (size_t)s;
+            const float4 q0 = ps[0], meta = ps[1];
+            const int w4 = f2i(meta.x), type = w4 & 15, xf = (w4 >> 8) - 1;
+            Ray rf = r;
+            if (xf >= 0) rf = to_object_rec<EXT_NONE>(sc, ps[2], ps[3], r);
+            float t;
+            const int32_t id = f2i(meta.z);
+            if (rect_test_lane(type, q0, meta.w, rf, t_min, t_max, &t) && id > floor_id) consider(best, t, id, (int32_t)s);
+        }
+        uint32_t others = ~rects & (cn == 32u ? 0xffffffffu : (1u << cn) - 1u);      // wave-uniform
+        int frame_xf = -2;
+        Ray rf = r;
+        while (others != 0u) {   // phase 2, everything else: the exact test, wave-uniform slot index as before
+            const uint32_t i = (uint32_t)__builtin_ctz(others), s = s0 + i;
+            others &= others - 1u;
+            const SlotRec cu = load_slot(sc, s);
+            const int w4 = f2i(cu.meta.x), xf = (w4 >> 8) - 1;
+            if (xf != frame_xf) {
+                frame_xf = xf;
+                rf = xf < 0 ? r : (type_has_inline_xform(w4 & 15) ? to_object_rec<EXT>(sc, cu.q2, cu.q3, r) : to_object<EXT>(sc, xf, r));
+            }
+            float t; int32_t id;
+            if (slot_hit_rec<STATS, EXT>(sc, s, cu, r, t_min, t_max, &t, &id, cnt, true, rf) && id > floor_id) consider(best, t, id, (int32_t)s);
+        }
+    }
+}
+
 // Rays the BVH cannot serve with reference semantics: anything non-finite, or a null direction.
 // NaN hit distances are ACCEPTED by the reference's comparisons (sphere.rs:61-65,
 // rectangles.rs:25-32) and the list fold then keeps the last such object; those rays take the
@@ -679,7 +847,7 @@ RT_DEV bool ray_is_finite(const Ray &r) {
 // Because slots are not stored in list order this runs as two passes over all slots: the fold's
 // result is the minimum (ties -> later) over the candidates that come after the last candidate
 // with an unordered (NaN) t, or that NaN candidate itself if it is the last one.
-template <bool STATS>
+template <bool STATS, int EXT = EXT_ALL>
 RT_DEV void closest_hit_exhaustive(const DScene &sc, const Ray &r, float t_min, float t_max, const float *med_t, const bool *med_ok,
                                    Hit &best, Counters &cnt) {
     int32_t last_nan_id = -1, last_nan_slot = 0;
@@ -687,11 +855,11 @@ RT_DEV void closest_hit_exhaustive(const DScene &sc, const Ray &r, float t_min, 
     int32_t last_id = -1;
     for (uint32_t s = 0; s < sc.n_slots; ++s) {
         float t; int32_t id;
-        if (!slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt)) continue;
+        if (!slot_hit<STATS, EXT>(sc, s, r, t_min, t_max, &t, &id, cnt)) continue;
         if (id > last_id) last_id = id;
         if (t != t && id > last_nan_id) { last_nan_id = id; last_nan_slot = (int32_t)s; last_nan_t = t; }
     }
-    for (uint32_t m = 0; m < sc.n_media; ++m) {
+    for (uint32_t m = 0; (EXT & EXT_MEDIA) && m < sc.n_media; ++m) {
         if (!med_ok[m]) continue;
         int32_t id = f2i(sc.media[2 * m + 1].z);
         if (id > last_id) last_id = id;
@@ -703,11 +871,11 @@ RT_DEV void closest_hit_exhaustive(const DScene &sc, const Ray &r, float t_min, 
     bool any = false;
     for (uint32_t s = 0; s < sc.n_slots; ++s) {
         float t; int32_t id;
-        if (!slot_hit<false>(sc, s, r, t_min, t_max, &t, &id, cnt)) continue;
+        if (!slot_hit<false, EXT>(sc, s, r, t_min, t_max, &t, &id, cnt)) continue;
         if (id <= last_nan_id) continue;
         if (!any || t < best.t || (t == best.t && id > best.id)) { best.t = t; best.id = id; best.slot = (int32_t)s; any = true; }
     }
-    for (uint32_t m = 0; m < sc.n_media; ++m) {
+    for (uint32_t m = 0; (EXT & EXT_MEDIA) && m < sc.n_media; ++m) {
         if (!med_ok[m]) continue;
         int32_t id = f2i(sc.media[2 * m + 1].z);
         if (id <= last_nan_id) continue;
@@ -718,7 +886,7 @@ RT_DEV void closest_hit_exhaustive(const DScene &sc, const Ray &r, float t_min, 
 
 // world.hit(r, t_min, t_max): surfaces through the BVH, media in list order (they draw random
 // numbers), everything folded with list semantics.  `with_media` = false for the parity hook.
-template <bool STATS>
+template <bool STATS, int EXT = EXT_ALL>
 RT_DEV bool closest_hit(const DScene &sc, const Ray &r, float t_min, float t_max, bool with_media, rts::Rng &rng, Hit &best,
                         const Stack &stack, Counters &cnt) {
     float med_t[RT_MAX_MEDIA];
@@ -726,10 +894,10 @@ RT_DEV bool closest_hit(const DScene &sc, const Ray &r, float t_min, float t_max
 #pragma unroll
     for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m) {
         med_ok[m] = false; med_t[m] = 0.0f;
-        if (with_media && m < sc.n_media) med_ok[m] = medium_hit<STATS>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
+        if ((EXT & EXT_MEDIA) && with_media && m < sc.n_media) med_ok[m] = medium_hit<STATS>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
     }
     if (!ray_is_finite(r)) {
-        closest_hit_exhaustive<STATS>(sc, r, t_min, t_max, med_t, med_ok, best, cnt);
+        closest_hit_exhaustive<STATS, EXT>(sc, r, t_min, t_max, med_t, med_ok, best, cnt);
         return best.id >= 0;
     }
     // A finite ray gets a NaN distance from exactly one kind of leaf: a rectangle whose plane
@@ -742,28 +910,24 @@ RT_DEV bool closest_hit(const DScene &sc, const Ray &r, float t_min, float t_max
         for (uint32_t i = 0; i < sc.n_rects; ++i) {
             float t; int32_t id;
             uint32_t s = sc.rects[i];
-            if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt) && t != t && id > floor_id) { floor_id = id; nan_slot = (int32_t)s; nan_t = t; }
+            if (slot_hit<STATS, EXT>(sc, s, r, t_min, t_max, &t, &id, cnt) && t != t && id > floor_id) { floor_id = id; nan_slot = (int32_t)s; nan_t = t; }
         }
     best.t = t_max; best.id = -1; best.slot = 0;
     bool any = false;
     // t == t_max is accepted by every leaf (e.g. `t > t_max` rejects, rectangles.rs:25), so the
     // first candidate must win even at t == t_max: start below any id.
-    for (uint32_t i = 0; i < sc.always_count; ++i) {
-        float t; int32_t id;
-        uint32_t s = sc.always_begin + i;
-        if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)s);
-    }
+    always_scan<STATS, EXT>(sc, r, t_min, t_max, floor_id, best, cnt);
     traverse<STATS>(sc, r, t_min, floor_id, best, stack, cnt);
     // MovingSphere boxes cover the shutter interval only; isotropic.rs:32 can hand a ray any "time"
     if (sc.n_moving && !(r.time >= 0.0f && r.time <= 1.0f))
         for (uint32_t i = 0; i < sc.n_moving; ++i) {
             float t; int32_t id;
             uint32_t s = sc.moving[i];
-            if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)s);
+            if (slot_hit<STATS, EXT>(sc, s, r, t_min, t_max, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)s);
         }
 #pragma unroll
     for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m)
-        if (med_ok[m] && f2i(sc.media[2 * m + 1].z) > floor_id) consider(best, med_t[m], f2i(sc.media[2 * m + 1].z), -(int32_t)(m + 1));
+        if ((EXT & EXT_MEDIA) && med_ok[m] && f2i(sc.media[2 * m + 1].z) > floor_id) consider(best, med_t[m], f2i(sc.media[2 * m + 1].z), -(int32_t)(m + 1));
     if (best.id < 0 && floor_id >= 0) { best.t = nan_t; best.id = floor_id; best.slot = nan_slot; }   // the NaN candidate was the last one
     any = best.id >= 0;
     return any;
@@ -784,7 +948,7 @@ struct Trav {
 };
 
 // world.hit() up to the point where the BVH walk starts.  Returns true if there is a walk to do.
-template <bool STATS>
+template <bool STATS, int EXT = EXT_ALL>
 RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max, rts::Rng &rng, Trav &tv, Counters &cnt) {
     float med_t[RT_MAX_MEDIA];
     bool med_ok[RT_MAX_MEDIA];
@@ -792,48 +956,32 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
 #pragma unroll
     for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m) {
         med_ok[m] = false; med_t[m] = 0.0f;
-        if (m < sc.n_media) med_ok[m] = medium_hit<STATS>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
+        if ((EXT & EXT_MEDIA) && m < sc.n_media) med_ok[m] = medium_hit<STATS>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
     }
     RG_END(RG_B_MEDIA);
     tv.floor_id = -1; tv.sp = 0; tv.ref = RT_BVH_EMPTY;
     if (!ray_is_finite(r)) {
-        closest_hit_exhaustive<STATS>(sc, r, t_min, t_max, med_t, med_ok, tv.best, cnt);
+        closest_hit_exhaustive<STATS, EXT>(sc, r, t_min, t_max, med_t, med_ok, tv.best, cnt);
         return false;
     }
     if (r.d.x == 0.0f || r.d.y == 0.0f || r.d.z == 0.0f)
         for (uint32_t i = 0; i < sc.n_rects; ++i) {
             float t; int32_t id;
-            if (slot_hit<STATS>(sc, sc.rects[i], r, t_min, t_max, &t, &id, cnt) && t != t && id > tv.floor_id) tv.floor_id = id;
+            if (slot_hit<STATS, EXT>(sc, sc.rects[i], r, t_min, t_max, &t, &id, cnt) && t != t && id > tv.floor_id) tv.floor_id = id;
         }
     tv.best.t = t_max; tv.best.id = -1; tv.best.slot = 0;
     RG_BEGIN(RG_B_ALWAYS);
-    if (sc.always_count) {   // the slot index is wave-uniform: fetch slot i+1 while slot i is tested
-        SlotRec nx = load_slot(sc, sc.always_begin);
-        int frame_xf = -1;   // consecutive slots under one transform (the six sides of a block) share the transformed ray
-        Ray r_frame = r;
-        for (uint32_t i = 0; i < sc.always_count; ++i) {
-            const SlotRec cu = nx;
-            const uint32_t s = sc.always_begin + i;
-            if (i + 1 < sc.always_count) nx = load_slot(sc, s + 1);
-            const int w4 = f2i(cu.meta.x), xf = (w4 >> 8) - 1;   // wave-uniform
-            if (xf != frame_xf) {
-                frame_xf = xf;
-                r_frame = xf < 0 ? r : (type_has_inline_xform(w4 & 15) ? to_object_rec(sc, cu.q2, cu.q3, r) : to_object(sc, xf, r));
-            }
-            float t; int32_t id;
-            if (slot_hit_rec<STATS>(sc, s, cu, r, t_min, t_max, &t, &id, cnt, &r_frame) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)s);
-        }
-    }
+    always_scan<STATS, EXT>(sc, r, t_min, t_max, tv.floor_id, tv.best, cnt);
     RG_END(RG_B_ALWAYS);
     if (sc.n_moving && !(r.time >= 0.0f && r.time <= 1.0f))
         for (uint32_t i = 0; i < sc.n_moving; ++i) {
             float t; int32_t id;
             uint32_t s = sc.moving[i];
-            if (slot_hit<STATS>(sc, s, r, t_min, t_max, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)s);
+            if (slot_hit<STATS, EXT>(sc, s, r, t_min, t_max, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)s);
         }
 #pragma unroll
     for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m)
-        if (med_ok[m] && f2i(sc.media[2 * m + 1].z) > tv.floor_id) consider(tv.best, med_t[m], f2i(sc.media[2 * m + 1].z), -(int32_t)(m + 1));
+        if ((EXT & EXT_MEDIA) && med_ok[m] && f2i(sc.media[2 * m + 1].z) > tv.floor_id) consider(tv.best, med_t[m], f2i(sc.media[2 * m + 1].z), -(int32_t)(m + 1));
     if (sc.root_ref == RT_BVH_EMPTY) return false;
     float dx = fabsf(r.d.x) < 1.0e-30f ? 1.0e-30f : r.d.x;
     float dy = fabsf(r.d.y) < 1.0e-30f ? 1.0e-30f : r.d.y;
@@ -847,7 +995,7 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
 template <bool STATS>
 RT_DEV void trav_node_step(const DScene &sc, float t_min, Trav &tv, const Stack &stack, Counters &cnt) {
     if (STATS) cnt.node_visits += 1;
-    tv.ref = node4_visit(sc, tv.ref, tv.inv, tv.oi, t_min, tv.best.t, stack, tv.sp);
+    tv.ref = node4_visit<STATS>(sc, tv.ref, tv.inv, tv.oi, t_min, tv.best.t, stack, tv.sp, cnt);
 }
 
 template <bool STATS, int EXT>
@@ -863,13 +1011,13 @@ RT_DEV void trav_leaf_step(const DScene &sc, const Ray &r, float t_min, Trav &tv
 }
 
 // After the walk: if nothing came after the last NaN candidate, that candidate is the hit.
-template <bool STATS>
+template <bool STATS, int EXT = EXT_ALL>
 RT_DEV void finish_trace(const DScene &sc, const Ray &r, float t_min, float t_max, Trav &tv, Counters &cnt) {
     if (tv.best.id >= 0 || tv.floor_id < 0) return;
     for (uint32_t i = 0; i < sc.n_rects; ++i) {
         float t; int32_t id;
         uint32_t s = sc.rects[i];
-        if (slot_hit<false>(sc, s, r, t_min, t_max, &t, &id, cnt) && id == tv.floor_id) { tv.best.t = t; tv.best.id = id; tv.best.slot = (int32_t)s; }
+        if (slot_hit<false, EXT>(sc, s, r, t_min, t_max, &t, &id, cnt) && id == tv.floor_id) { tv.best.t = t; tv.best.id = id; tv.best.slot = (int32_t)s; }
     }
 }
 
@@ -914,7 +1062,9 @@ RT_DEV float perlin_turbulence(const uint32_t *tab, V3 p, int depth) {  // perli
     return fabsf(acc);
 }
 
+template <int EXT = EXT_ALL>
 RT_DEV bool texture_needs_uv(const DScene &sc, int tex) {
+    if (!(EXT & EXT_IMAGE)) return false;     // u, v only matter to an image texture
     for (int level = 0; level < 8; ++level) {
         int type = f2i(sc.textures[2 * tex].x);
         if (type == RTG_TEX_IMAGE) return true;
@@ -928,7 +1078,7 @@ RT_DEV bool texture_needs_uv(const DScene &sc, int tex) {
     return true;
 }
 
-template <bool STATS>
+template <bool STATS, int EXT = EXT_ALL>
 RT_DEV V3 texture_value(const DScene &sc, int tex, float u, float v, V3 p, Counters &cnt) {
     for (int level = 0; level < 16; ++level) {
         float4 a = sc.textures[2 * tex], b = sc.textures[2 * tex + 1];
@@ -941,12 +1091,13 @@ RT_DEV V3 texture_value(const DScene &sc, int tex, float u, float v, V3 p, Count
             tex = sines < 0.0f ? f2i(b.x) : f2i(b.y);
             continue;
         }
-        if (type == RTG_TEX_NOISE) {  // noise_texture.rs:28-30
+        if ((EXT & EXT_NOISE) && type == RTG_TEX_NOISE) {  // noise_texture.rs:28-30
             const uint32_t *tab = (sc.perlin_lds && f2i(b.x) == 0) ? sc.perlin_lds : sc.perlin + (size_t)f2i(b.x) * RT_PERLIN_WORDS;
             float k = 1.0f + pm::sinf_(b.z * p.z + 10.0f * perlin_turbulence(tab, p, 7));
             float g = 1.0f * 0.5f;
             return v3(g * k, g * k, g * k);
         }
+        if (!(EXT & EXT_IMAGE)) return v3(0.0f, 0.0f, 0.0f);
         // image_texture.rs:50-86
         int off = f2i(b.x);
         if (off < 0) return v3(0.0f, 1.0f, 1.0f);
@@ -1082,13 +1233,13 @@ RT_DEV float schlick(float cosine, float ior) {  // types.rs:165-169
 // Texture of a material.  Word 7 of the DEVICE copy of a material record (rt_scene_upload) holds the kind of
 // its texture + 1, and for a solid colour words 2..4 hold that colour: most bounces then need no texture fetch
 // (one link less in the slot -> material -> texture chain of dependent loads).
-template <bool STATS>
+template <bool STATS, int EXT = EXT_ALL>
 RT_DEV V3 material_texture(const DScene &sc, float4 ma, float4 mb, float u, float v, V3 p, Counters &cnt) {
     if (f2i(mb.w) == RTG_TEX_SOLID + 1) {
         if (STATS) cnt.tex_evals[RTG_TEX_SOLID] += 1;
         return v3(ma.z, ma.w, mb.x);
     }
-    return texture_value<STATS>(sc, f2i(ma.y), u, v, p, cnt);
+    return texture_value<STATS, EXT>(sc, f2i(ma.y), u, v, p, cnt);
 }
 
 struct Path {
@@ -1100,7 +1251,7 @@ struct Path {
 
 // Everything ray_color does after world.hit() returned `best` (camera.rs:264-308).  Returns true
 // while the path continues (ps.ray is then the scattered ray and ps.depth is one less).
-template <bool STATS>
+template <bool STATS, int EXT = EXT_ALL>
 RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background, rts::Rng &rng, Counters &cnt) {
     if (best.id < 0) {
         ps.radiance = ps.radiance + ps.throughput * background;
@@ -1108,7 +1259,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
     }
     if (STATS) cnt.accepted += 1;
     Rec rec;
-    if (best.slot < 0) {  // ConstantMedium record (constant_medium.rs:85-93)
+    if ((EXT & EXT_MEDIA) && best.slot < 0) {  // ConstantMedium record (constant_medium.rs:85-93)
         uint32_t m = (uint32_t)(-best.slot - 1);
         float4 mb = sc.media[2 * m + 1];
         rec.t = best.t;
@@ -1118,7 +1269,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
         rec.material = f2i(mb.y);
         rec.u = 0.0f; rec.v = 0.0f;
         int tex = f2i(sc.materials[2 * rec.material].y);
-        if (texture_needs_uv(sc, tex)) {  // u,v of the boundary's first hit
+        if (texture_needs_uv<EXT>(sc, tex)) {  // u,v of the boundary's first hit
             float4 ma = sc.media[2 * m];
             float t1;
             V3 c = v3(ma.x, ma.y, ma.z);
@@ -1128,9 +1279,9 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
         int mat = f2i(sc.slots[4 * (size_t)best.slot + 1].y);
         float4 ma = sc.materials[2 * mat];
         int tkind = f2i(sc.materials[2 * mat + 1].w);   // 0 untextured, kind + 1 otherwise
-        bool want_uv = tkind > RTG_TEX_SOLID + 1 && texture_needs_uv(sc, f2i(ma.y));
+        bool want_uv = tkind > RTG_TEX_SOLID + 1 && texture_needs_uv<EXT>(sc, f2i(ma.y));
         RG_BEGIN(RG_RECORD);
-        rec = slot_record(sc, (uint32_t)best.slot, ps.ray, best.t, want_uv, 0.001f, INFINITY);
+        rec = slot_record<EXT>(sc, (uint32_t)best.slot, ps.ray, best.t, want_uv, 0.001f, INFINITY);
         RG_END(RG_RECORD);
     }
     float4 ma = sc.materials[2 * rec.material], mb = sc.materials[2 * rec.material + 1];
@@ -1141,7 +1292,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
     case RTG_MAT_DIFFUSE_LIGHT: {  // diffuse_light.rs:43-56; scatter = None -> return emitted
         RG_BEGIN(RG_EMIT);
         if (rec.front_face) {
-            V3 e = material_texture<STATS>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
+            V3 e = material_texture<STATS, EXT>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
             ps.radiance = ps.radiance + ps.throughput * e;
         }
         RG_END(RG_EMIT);
@@ -1178,9 +1329,10 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
         break;
     }
     case RTG_MAT_ISOTROPIC: {  // isotropic.rs:26-35
+        if (!(EXT & EXT_MEDIA)) return false;     // (only a ConstantMedium carries this material)
         RG_BEGIN(RG_ISO);
         V3 dir = random_in_unit_sphere(rng);
-        V3 att = material_texture<STATS>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
+        V3 att = material_texture<STATS, EXT>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
         ps.throughput = ps.throughput * att;
         ps.ray = Ray{rec.p, dir, rec.t};  // sic: time = hit t
         RG_END(RG_ISO);
@@ -1189,7 +1341,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
     default: {  // Lambertian: lambertian.rs:33-51 + camera.rs:271-301
         RG_BEGIN(RG_LAMBERT);
         RG_BEGIN(RG_TEXTURE);
-        V3 albedo = material_texture<STATS>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
+        V3 albedo = material_texture<STATS, EXT>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
         RG_END(RG_TEXTURE);
         Onb uvw = onb_from(rec.normal);
         V3 dir;

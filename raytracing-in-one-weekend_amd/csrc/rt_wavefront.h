@@ -36,7 +36,8 @@ struct PathQ {
     float4 *hit;     // best.t, best.id, best.slot, floor_id
 };
 
-enum : uint32_t { WF_DEPTH_MASK = 0xffu, WF_ALIVE = 0x100u, WF_WALK = 0x200u };
+// remaining depth in 16 bits (rt_render refuses max_ray_depth > RT_MAX_RAY_DEPTH = 65535), then the two state bits
+enum : uint32_t { WF_DEPTH_MASK = 0xffffu, WF_ALIVE = 0x10000u, WF_WALK = 0x20000u };
 
 // The pool is cut into RT_WF_SHARDS shards of `cap` entries, each with its own counters in its own
 // 256-byte line: an atomic on one address costs several ns whoever issues it, so the per-wave
@@ -130,6 +131,7 @@ RT_DEV void flush_counters(const Counters &cnt, uint32_t paths, unsigned long lo
     for (int i = 0; i < 4; ++i) vals[10 + P + i] = cnt.tex_evals[i];
     vals[14 + P] = cnt.accepted;
     for (int i = 0; i < 5; ++i) { vals[15 + P + i] = cnt.phase_lanes[i]; vals[20 + P + i] = cnt.phase_slots[i]; }
+    vals[25 + P] = cnt.box_tests;
     for (int i = 0; i < RT_STAT_WORDS; ++i) {
         uint32_t w = wave_sum(vals[i]);
         if ((threadIdx.x & 63u) == 0 && w) atomicAdd(&stats[i], (unsigned long long)w);
@@ -144,13 +146,16 @@ RT_DEV void flush_counters(const Counters &cnt, uint32_t paths, unsigned long lo
 #ifndef RT_WF_GEN_WAVES
 #define RT_WF_GEN_WAVES 1       // min waves per SIMD the generate kernel is compiled for (1 = the compiler's choice: 112 VGPRs, 4 waves)
 #endif
-template <bool STATS>
+template <bool STATS, int EXT>
 __global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScene sc, WfArgs w, PathQ nxt, WfCounters *ctr, uint32_t it,
                                                           float4 *__restrict__ samples, uint32_t *status, unsigned long long *stats,
                                                           uint32_t *pixel_rays) {
     const WfCounters *c = ctr + (it % RT_WF_RING);
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t shard = (blockIdx.x * blockDim.x) / w.cap, off0 = (blockIdx.x * blockDim.x) - shard * w.cap;   // block-uniform
+    // grid = (chunks of 256 entries per shard, 64 shards).  The host launches cap / 256 chunks while items are being handed
+    // out and, once the pool only shrinks, as many as the largest shard last reported needs (status[3]): an iteration on a
+    // nearly empty pool then dispatches 64 workgroups instead of 16 384 that look at a counter and leave.
+    const uint32_t shard = blockIdx.y, off0 = blockIdx.x * blockDim.x;   // block-uniform
+    const uint32_t j = shard * w.cap + off0 + threadIdx.x;
     const uint32_t n_surv = c->sh[shard].n_surv;
     if (off0 != 0 && off0 + blockDim.x <= n_surv) return;   // block-uniform: only survivors here (most blocks in steady state)
     __shared__ uint32_t s_sum[3];
@@ -159,6 +164,11 @@ __global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScen
         const uint32_t before = wave_sum(threadIdx.x < shard ? w.cap - sv : 0u);
         const uint32_t all = wave_sum(w.cap - sv), surv = wave_sum(sv);
         if (threadIdx.x == 0) { s_sum[0] = before; s_sum[1] = all; s_sum[2] = surv; }
+        if (off0 == 0 && shard == 0) {     // largest shard of the next iteration for the host's grid sizing, once all items are out
+            uint32_t mx = sv;
+            for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_down((int)mx, o, 64); mx = other > mx ? other : mx; }
+            if (threadIdx.x == 0) status[3] = c->sh[0].item_head == w.n_items ? mx : 0xffffffffu;   // (nothing new in this iteration: next count_in = n_surv)
+        }
     }
     __syncthreads();
     const uint32_t item_head = c->sh[0].item_head;
@@ -211,7 +221,7 @@ __global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScen
         p.ps.radiance = v3(0.0f, 0.0f, 0.0f);
         p.ps.depth = w.a.max_depth;
         if (STATS) { cnt.rays += 1; if (pixel_rays) atomicAdd(&pixel_rays[p.pixel], 1u); }
-        const bool walk = begin_trace<STATS>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt);
+        const bool walk = begin_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt);
         store_entry(nxt, e, p, tv, walk);
     }
     if (STATS || kTimers) flush_counters<STATS>(cnt, inside ? 1u : 0u, stats);
@@ -325,12 +335,12 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
 #ifndef RT_WF_SHADE_WAVES
 #define RT_WF_SHADE_WAVES 1
 #endif
-template <bool STATS>
+template <bool STATS, int EXT>
 __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene sc_in, WfArgs w, PathQ cur, PathQ nxt, WfCounters *ctr, uint32_t it,
                                                        float4 *__restrict__ samples, unsigned long long *stats, uint32_t *pixel_rays) {
     DScene sc = sc_in;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t shard = (blockIdx.x * blockDim.x) / w.cap, off0 = (blockIdx.x * blockDim.x) - shard * w.cap;   // block-uniform
+    const uint32_t shard = blockIdx.y, off0 = blockIdx.x * blockDim.x;   // block-uniform; grid as in wf_generate_kernel
+    uint32_t i = shard * w.cap + off0 + threadIdx.x;
     WfShard *c = &ctr[it % RT_WF_RING].sh[shard];
     const uint32_t n = c->count_in;
     if (off0 >= n) return;   // block-uniform
@@ -349,7 +359,7 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
     {
         __shared__ uint32_t s_count[8][4];
         __shared__ uint16_t s_perm[256];
-        __shared__ uint32_t s_perlin[RT_PERLIN_WORDS];
+        __shared__ uint32_t s_perlin[(EXT & EXT_NOISE) ? RT_PERLIN_WORDS : 1];
         const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
         uint32_t key = 7u;
         if (off0 + threadIdx.x < n) {
@@ -383,12 +393,12 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
         s_perm[before + rank] = (uint16_t)threadIdx.x;
         // A noise texture is 7 octaves x 8 corners of dependent table look-ups (perlin.rs:84-123): blocks that
         // hold such hits (key 2) copy the 6 KB table into LDS first (block-uniform decision).
-        if (s_count[2][0] + s_count[2][1] + s_count[2][2] + s_count[2][3] != 0u) {
+        if ((EXT & EXT_NOISE) && s_count[2][0] + s_count[2][1] + s_count[2][2] + s_count[2][3] != 0u) {
             for (uint32_t k = threadIdx.x; k < RT_PERLIN_WORDS; k += blockDim.x) s_perlin[k] = sc.perlin[k];
             sc.perlin_lds = s_perlin;
         }
         __syncthreads();
-        i = blockIdx.x * blockDim.x + s_perm[threadIdx.x];
+        i = shard * w.cap + off0 + s_perm[threadIdx.x];
         if (off0 + s_perm[threadIdx.x] < n) { d = cur.ray_d[i]; flags = __float_as_uint(d.w); }
     }
 #else
@@ -411,9 +421,9 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
         p.rng.inc = (((((uint64_t)p.pixel << 24) ^ (uint64_t)p.sample)) << 1u) | 1u;   // rts::path_rng's stream
         tv.best.t = h.x; tv.best.id = f2i(h.y); tv.best.slot = f2i(h.z); tv.floor_id = f2i(h.w);
         RG_END(RG_LOAD);
-        finish_trace<STATS>(sc, p.ps.ray, 0.001f, INFINITY, tv, cnt);
+        finish_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, tv, cnt);
         RG_BEGIN(RG_SHADE_ALL);
-        const bool cont = shade_hit<STATS>(sc, p.ps, tv.best, background, p.rng, cnt);
+        const bool cont = shade_hit<STATS, EXT>(sc, p.ps, tv.best, background, p.rng, cnt);
         RG_END(RG_SHADE_ALL);
         if (cont && p.ps.depth > 0) survive = true;
         else samples[p.item] = make_float4(p.ps.radiance.x, p.ps.radiance.y, p.ps.radiance.z, 0.0f);
@@ -422,7 +432,7 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
     if (survive) {
         if (STATS) { cnt.rays += 1; if (pixel_rays) atomicAdd(&pixel_rays[p.pixel], 1u); }
         RG_BEGIN(RG_BEGIN_ALL);
-        walk = begin_trace<STATS>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt);
+        walk = begin_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt);
         RG_END(RG_BEGIN_ALL);
     }
     RG_BEGIN(RG_STORE);
@@ -507,7 +517,7 @@ __global__ void __launch_bounds__(64) wf_tail_kernel(DScene sc, WfArgs w, PathQ 
                 const unsigned long long m_node = __ballot(alive && walk && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
                 if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
                     phase_count<STATS>(cnt, PH_LEAF, at_leaf);
-                    if (at_leaf) trav_leaf_step<STATS, EXT>(sc, p.ps.ray, T_MIN, tv, stack, cnt);
+                    if (at_leaf) trav_leaf_step<STATS, EXT & (EXT_XFORM | EXT_TRI)>(sc, p.ps.ray, T_MIN, tv, stack, cnt);
                 } else if (m_node == 0ull) {
                     break;
                 }
@@ -515,8 +525,8 @@ __global__ void __launch_bounds__(64) wf_tail_kernel(DScene sc, WfArgs w, PathQ 
             phase_count<STATS>(cnt, PH_SHADE, alive);
             bool survive = false;
             if (alive) {
-                finish_trace<STATS>(sc, p.ps.ray, T_MIN, INFINITY, tv, cnt);
-                survive = shade_hit<STATS>(sc, p.ps, tv.best, background, p.rng, cnt) && p.ps.depth > 0;
+                finish_trace<STATS, EXT>(sc, p.ps.ray, T_MIN, INFINITY, tv, cnt);
+                survive = shade_hit<STATS, EXT>(sc, p.ps, tv.best, background, p.rng, cnt) && p.ps.depth > 0;
                 if (!survive) {
                     samples[p.item] = make_float4(p.ps.radiance.x, p.ps.radiance.y, p.ps.radiance.z, 0.0f);
                     alive = false;
@@ -525,7 +535,7 @@ __global__ void __launch_bounds__(64) wf_tail_kernel(DScene sc, WfArgs w, PathQ 
             phase_count<STATS>(cnt, PH_BEGIN, survive);
             if (survive) {
                 if (STATS) { cnt.rays += 1; if (pixel_rays) atomicAdd(&pixel_rays[p.pixel], 1u); }
-                walk = begin_trace<STATS>(sc, p.ps.ray, T_MIN, INFINITY, p.rng, tv, cnt);
+                walk = begin_trace<STATS, EXT>(sc, p.ps.ray, T_MIN, INFINITY, p.rng, tv, cnt);
             }
         }
     }

@@ -107,6 +107,35 @@ def test_a_node_with_a_child_out_of_range_is_found_on_the_host(rt, ctx):
     assert st == RT_E_INVALID and "child out of range" in msg
 
 
+def test_a_cyclic_tree_or_an_under_declared_stack_is_found_on_the_host(rt, ctx):
+    """The walk pushes unchecked and its persistent waves end only when every stack has drained: a cycle would hang the GPU,
+    a stack_depth below the tree's need would write past the LDS stack.  rt_scene_upload walks the tree and refuses both."""
+    b, flat, params, camera, sampler = ctx
+    b.upload_scene(flat)
+    b.upload_sampler(sampler)
+    ref, _ = b.render(params, camera)
+    d = copy_of(flat.desc)
+    nn = int(d.n_bvh_nodes)
+    nodes = np.ctypeslib.as_array(flat.desc.bvh_nodes, shape=(nn * 16,)).copy()
+    refs = nodes.view(np.int32).reshape(nn, 16)[:, 12:16]
+    inner = [(i, c) for i in range(nn) for c in range(4) if 0 <= refs[i, c] < nn]
+    assert inner, "C1's tree has more than one level"
+    i, c = inner[-1]
+    saved = refs[i, c]
+    refs[i, c] = int(d.bvh_root_ref)                                            # a back edge to the root: a cycle
+    d.bvh_nodes = nodes.ctypes.data_as(rt._ffi.c_float_p)
+    st, msg = status_and_text(b, b._L.rt_scene_upload(b._h, C.byref(d)))
+    assert st == RT_E_INVALID and "reachable twice" in msg, (st, msg)
+    refs[i, c] = saved
+    d.bvh_stack_depth = 3                                                       # one inner level's worth: C1 has several
+    st, msg = status_and_text(b, b._L.rt_scene_upload(b._h, C.byref(d)))
+    assert st == RT_E_INVALID and "too small" in msg, (st, msg)
+    d.bvh_stack_depth = flat.desc.bvh_stack_depth                               # the intact copy is accepted
+    assert b._L.rt_scene_upload(b._h, C.byref(d)) == 0
+    again, _ = b.render(params, camera)
+    assert np.array_equal(again.view(np.uint32), ref.view(np.uint32))
+
+
 def test_bad_sampler_tables_are_refused(rt, ctx):
     b, flat, params, camera, sampler = ctx
     d = copy_of(sampler.desc)
@@ -148,6 +177,7 @@ def test_bad_render_parameters_leave_the_image_alone(rt, ctx):
         (changed(spp_begin=2, spp_count=sampler.spp), RT_E_INVALID, "sample range"),
         (changed(spp_begin=-1), RT_E_INVALID, "sample range"),
         (changed(projection=9), RT_E_INVALID, "projection"),
+        (changed(max_ray_depth=65536), RT_E_INVALID, "max_ray_depth"),
         (changed(collect_stats=1), RT_E_INVALID, "stats"),
         (changed(cancel=C.pointer(cancel)), RT_E_CANCELLED, "cancelled"),
     ]

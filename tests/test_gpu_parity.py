@@ -283,3 +283,26 @@ def test_many_transformed_blocks_go_through_the_bvh(rt, gpu):
     gpu.upload_scene(s.flatten(device_bvh=True))
     img2, _ = gpu.render(params, camera)
     assert np.array_equal(img2.view(np.uint32), img.view(np.uint32))
+
+
+def test_paths_deeper_than_255_bounces(rt, gpu):
+    """max_ray_depth is an unbounded i32 in the reference (camera.rs:253-262).  Inside a closed diffuse sphere with a tiny
+    emitter and a zero-emission `lights` rectangle that is not in `world` (Book-1's arrangement, main.rs:187-196; here it
+    lies inside the sphere, so a light-sampled direction still ends on the wall) almost every path runs to the depth limit: at depth 300 every such sample must issue 300 rays, as the oracle's does (a path's remaining depth once
+    travelled in 8 bits and wrapped at 256)."""
+    s = rt.host.Scene()
+    wall = s.lambertian(s.solid(0.9, 0.9, 0.9))
+    lamp = s.diffuse_light(s.solid(40.0, 30.0, 20.0))
+    world = [s.sphere((0, 0, 0), 100.0, wall), s.sphere((30, 0, 0), 2.0, lamp)]
+    for k in range(30):      # enough leaves for a BVH walk (more than the 24 a flat scan takes)
+        world.append(s.sphere((-40 + 3.0 * k, -50 + 2.0 * k, 40 - 2.5 * k), 1.5, wall))
+    s.set_roots(s.hittable_list(world), s.hittable_list([s.xz_rect(-10, 10, -10, 10, 50, s.diffuse_light(s.solid(0, 0, 0)))]))
+    _, params, _, _ = rt.configs.build("C2", image_width=24, samples_per_pixel=4)
+    params = params.replace(max_ray_depth=300, look_from=(0.0, 0.0, -60.0), look_at=(0.0, 0.0, 0.0), vertical_fov=60.0)
+    camera = params.camera()
+    sampler = rt.host.MultiJitteredSampler(4, seed=rt.configs.SEED)
+    gpu.upload_scene(s.flatten())
+    gpu.upload_sampler(sampler)
+    g_img, c_img, stats = compare_images(rt, gpu, O.OracleScene(s), params, camera, sampler)
+    assert stats["rays"] > 200 * stats["paths"], "most paths should reach the depth limit"
+    assert stats["node_visits"] > 0 and stats["box_tests"] >= stats["node_visits"]
