@@ -82,6 +82,11 @@ class Bench:
         self.dev = torch.device("cuda", local_rank)
         self.gpu = rt.backend.HipBackend(local_rank)   # raises if the HIP library or the GPU is missing
         self.stream = torch.cuda.current_stream(self.dev)
+        # the frame's one exchange goes through the C-ABI (rt_comm_reduce_to_root = RCCL reduce on the render's stream);
+        # torch.distributed only carries the 128-byte communicator id, the barriers and the scalar sums of the report
+        self.comm = None
+        if dist is not None:
+            self.comm = rt.sharding.Communicator(self.gpu, rank, world, exchange=lambda box: dist.broadcast_object_list(box, src=0))
 
     def run(self, name, steps, warmup, spp=0, width=0, cpu=False):
         """One workload: upload, count rays (untimed), warm up, time `steps` frames.  Returns the result dict."""
@@ -125,8 +130,8 @@ class Bench:
         def step():
             acc.zero_()
             gpu.render_device(params, camera, acc.data_ptr(), sptr, spp_begin=spp_begin, spp_count=spp_count)
-            if dist is not None:
-                dist.reduce(acc, dst=0)   # RCCL over xGMI: per-GPU sums -> rank 0
+            if self.comm is not None:
+                self.comm.reduce_to_root(acc.data_ptr(), acc.numel(), 0, sptr)   # RCCL over xGMI: per-GPU sums -> rank 0
 
         for _ in range(warmup):
             step()
@@ -140,8 +145,8 @@ class Bench:
             ev[k][0].record(self.stream)
             gpu.render_device(params, camera, acc.data_ptr(), sptr, spp_begin=spp_begin, spp_count=spp_count)
             ev[k][1].record(self.stream)
-            if dist is not None:
-                dist.reduce(acc, dst=0)
+            if self.comm is not None:
+                self.comm.reduce_to_root(acc.data_ptr(), acc.numel(), 0, sptr)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -295,6 +300,8 @@ def main():
         if subs:
             out["workloads"] = subs
         print(json.dumps(out))
+    if B.comm is not None:
+        B.comm.close()
     if dist is not None:
         dist.destroy_process_group()
     B.gpu.close()

@@ -32,7 +32,7 @@ typedef enum rt_status {
     RT_OK                      =  0,
     RT_E_INVALID               = -1,  /* bad argument / inconsistent descriptor        */
     RT_E_HIP                   = -2,  /* a HIP runtime call failed                      */
-    RT_E_RCCL                  = -3,  /* reserved (collectives live in the host layer)  */
+    RT_E_RCCL                  = -3,  /* RCCL missing, or one of its calls failed (rt_comm_*, rt_group_*) */
     RT_E_OOM                   = -4,  /* device allocation failed                       */
     RT_E_UNSUPPORTED_PRIMITIVE = -5,  /* scene uses something the kernels do not cover  */
     RT_E_NO_DEVICE             = -6,  /* no usable GPU                                  */
@@ -275,6 +275,43 @@ int rt_trace_first_hit(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_mi
 #define RT_NOALLOC_SCRATCH_BYTES (8u << 20)
 int rt_trace_first_hit_noalloc(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_min, float t_max,
                                uint32_t *prim_id, float *t, float *normal3, uint8_t *front_face, float *uv2);
+
+/* ------------------------------------------------------------------- multi-GPU
+ * No counterpart in the reference (one process, one thread pool: main.rs:1314-1409).  The frame is sharded over GPUs by
+ * sample range (rt_render_params.spp_begin / spp_count; the RNG is keyed by the absolute sample index, so the image does not
+ * depend on how many GPUs rendered it) or by tile rectangle, every GPU accumulates into its own W*H*4 f32 buffer, and ONE
+ * RCCL reduce (sum, in place, to the root; xGMI gives every GPU a direct link to it) makes the frame.  RCCL is loaded on first
+ * use; without it these calls return RT_E_RCCL and everything else keeps working.
+ *
+ * One process per GPU (MPI / torchrun style): rank 0 calls rt_comm_unique_id and hands the 128 bytes to the other ranks by
+ * whatever channel the host has; every rank calls rt_comm_create (collective: returns when all `world` ranks have called it),
+ * renders its share with rt_render into a DEVICE buffer, then calls rt_comm_reduce_to_root on the same stream.  The call is
+ * asynchronous like the render; on `root` the buffer then holds the sum of all ranks' buffers, elsewhere it is unchanged. */
+#define RT_COMM_ID_BYTES 128
+#include <stddef.h>
+/* Device buffers for a host that has no HIP binding of its own (the Rust host): an accumulation image on the context's GPU,
+ * zeroed / read back in stream order (stream: hipStream_t, NULL = default; rt_device_read waits for the copy). */
+int rt_device_alloc(rt_ctx *ctx, size_t bytes, void **out_device_ptr);
+int rt_device_free(rt_ctx *ctx, void *device_ptr);
+int rt_device_zero(rt_ctx *ctx, void *device_ptr, size_t bytes, void *stream);
+int rt_device_read(rt_ctx *ctx, void *dst_host, const void *src_device, size_t bytes, void *stream);
+typedef struct rt_comm rt_comm;
+int rt_comm_unique_id(char id[RT_COMM_ID_BYTES]);
+int rt_comm_create(rt_ctx *ctx, const char id[RT_COMM_ID_BYTES], int rank, int world, rt_comm **out);
+int rt_comm_reduce_to_root(rt_comm *comm, float *rgba_sum_device, int64_t n_floats, int root, void *stream);
+void rt_comm_destroy(rt_comm *comm);
+
+/* One process, n GPUs (what a Rust host with one thread per GPU would use): a group owns one context per listed device and a
+ * communicator over them.  rt_group_ctx(g, i) is the context of device_ids[i] (owned by the group: do not rt_destroy it);
+ * upload the scene and sampler to each and render from one host thread per context.  rt_group_reduce_to_root takes the n
+ * device buffers (rgba_sums[i] on device i) and the n streams the renders were ordered on (NULL = default streams) and sums
+ * them into rgba_sums[root]; it returns when the reduce is queued on every stream. */
+typedef struct rt_group rt_group;
+int rt_group_create(const int *device_ids, int n, rt_group **out);
+int rt_group_size(const rt_group *g);
+rt_ctx *rt_group_ctx(rt_group *g, int i);
+int rt_group_reduce_to_root(rt_group *g, float *const *rgba_sums, int64_t n_floats, int root, void *const *streams);
+void rt_group_destroy(rt_group *g);
 
 /* Block until everything queued on `stream` (NULL = default) by this context is done. */
 int rt_synchronize(rt_ctx *ctx, void *stream);

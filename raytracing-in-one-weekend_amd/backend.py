@@ -143,6 +143,23 @@ class HipBackend:
             uv.ctypes.data_as(_ffi.c_float_p)))
         return pid, t, nrm, ff, uv
 
+    def device_alloc(self, nbytes):
+        """A device buffer on this context's GPU (rt_device_alloc): returns its address as an int."""
+        p = C.c_void_p()
+        self._check(self._L.rt_device_alloc(self._h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def device_free(self, ptr):
+        self._check(self._L.rt_device_free(self._h, ptr))
+
+    def device_zero(self, ptr, nbytes, stream_ptr=None):
+        self._check(self._L.rt_device_zero(self._h, ptr, int(nbytes), stream_ptr))
+
+    def device_read(self, ptr, shape, dtype=np.float32, stream_ptr=None):
+        out = np.empty(shape, dtype)
+        self._check(self._L.rt_device_read(self._h, out.ctypes.data, ptr, out.nbytes, stream_ptr))
+        return out
+
     def synchronize(self, stream_ptr=None):
         self._check(self._L.rt_synchronize(self._h, stream_ptr))
 

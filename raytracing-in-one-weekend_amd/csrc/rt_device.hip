@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "rt_bvh_build.h"
+#include "rt_device_internal.h"
 #include "rt_kernels.h"
 #include "rt_wavefront.h"
 
@@ -400,6 +401,18 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
 }
 
 }  // namespace
+
+namespace rtk_internal {
+int ctx_device(const rt_ctx *ctx) { return ctx->device; }
+int ctx_fail(rt_ctx *ctx, int status, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return fail(ctx, status, "%s", buf);
+}
+}  // namespace rtk_internal
 
 extern "C" {
 

@@ -342,6 +342,21 @@ def test_sample_range_sharding(rt):
         assert pos == spp and max(c for _, c in ranges) - min(c for _, c in ranges) <= 1
 
 
+def test_tile_sharding_covers_every_pixel_once(rt):
+    import numpy as np
+    for (w, h, block, world) in ((1200, 675, 32, 8), (600, 600, 8, 3), (37, 19, 16, 2), (64, 64, 64, 8)):
+        cover = np.zeros((h, w), np.int32)
+        counts = []
+        for r in range(world):
+            rects = rt.sharding.tile_rects(r, world, w, h, block)
+            counts.append(len(rects))
+            for x0, y0, x1, y1 in rects:
+                assert 0 <= x0 < x1 <= w and 0 <= y0 < y1 <= h
+                cover[y0:y1, x0:x1] += 1
+        assert (cover == 1).all()
+        assert max(counts) - min(counts) <= 1
+
+
 def test_c5_workload_is_the_4k_frame_split_over_eight_ranks(rt):
     # BASELINE configs[4]: 3840x2160 Book-2 final scene, 16k spp (128^2) sharded over 8 GPUs by sample range
     name, params, grid = rt.configs.workload("C5")

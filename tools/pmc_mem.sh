@@ -2,7 +2,7 @@
 # usage: tools/pmc_mem.sh TAG WORKLOAD SPP — texture-path counters (TA / TCP) of one bench step, per kernel
 TAG=$1; W=$2; SPP=$3
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -s KILL 120 rocprofv3 --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcm_${TAG} -- python3 bench.py --steps 1 --warmup 0 --no-cpu --workload $W --spp $SPP > gpurun_out/pmcm_${TAG}.json 2> gpurun_out/pmcm_${TAG}.err || exit 1
+timeout -s KILL 120 rocprofv3 --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcm_${TAG} -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-sub --workload $W --spp $SPP > gpurun_out/pmcm_${TAG}.json 2> gpurun_out/pmcm_${TAG}.err || exit 1
 python3 - <<PY
 import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
