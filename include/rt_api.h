@@ -305,7 +305,8 @@ void rt_comm_destroy(rt_comm *comm);
  * communicator over them.  rt_group_ctx(g, i) is the context of device_ids[i] (owned by the group: do not rt_destroy it);
  * upload the scene and sampler to each and render from one host thread per context.  rt_group_reduce_to_root takes the n
  * device buffers (rgba_sums[i] on device i) and the n streams the renders were ordered on (NULL = default streams) and sums
- * them into rgba_sums[root]; it returns when the reduce is queued on every stream. */
+ * them into rgba_sums[root]; it returns when the reduce is queued on every stream.  A group of one device needs no RCCL and its
+ * reduce is a no-op, so a host can use the group calls whatever the number of GPUs (integration/render_gpu.rs). */
 typedef struct rt_group rt_group;
 int rt_group_create(const int *device_ids, int n, rt_group **out);
 int rt_group_size(const rt_group *g);

@@ -58,11 +58,14 @@ int rth_add_block(rth_scene *s, const float p0[3], const float p1[3], int mtl);
 int rth_add_flip_face(rth_scene *s, int child);
 int rth_add_translate(rth_scene *s, int child, const float offset[3]);
 int rth_add_rotate_y(rth_scene *s, int child, float degrees);
+/* RotateY as the reference holds it after RotateY::new (transform.rs:57-62, 65-67): the host's own sin and cos */
+int rth_add_rotate_y_sincos(rth_scene *s, int child, float sin_theta, float cos_theta);
 int rth_add_bvh(rth_scene *s, const int32_t *children, int n);
 int rth_add_list(rth_scene *s, const int32_t *children, int n);
 int rth_add_constant_medium(rth_scene *s, int boundary, int albedo_tex, float density);
 /* TriangleMesh::new: vertices are IMPORTED (object-space) vertices, obj2world row-major 4x4
- * (math/src/mat4.rs:20-41); the call bakes them to world space as triangle_mesh.rs:48-72. */
+ * (math/src/mat4.rs:20-41); the call bakes them to world space as triangle_mesh.rs:48-72.
+ * obj2world = NULL: the vertices are already baked (TriangleMesh::vertices as the reference keeps them) and are taken as is. */
 int rth_add_triangle_mesh(rth_scene *s, const rtg_vertex *verts, uint32_t n_verts, const uint32_t *indices,
                           uint32_t n_indices, const rtg_mesh_node *nodes, uint32_t n_nodes,
                           const float obj2world[16], int mtl);

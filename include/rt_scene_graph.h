@@ -38,7 +38,7 @@ enum rtg_node_type {
     RTG_BLOCK           = 5,  /* block.rs:17-109            f = p0xyz, p1xyz                       */
     RTG_FLIP_FACE       = 6,  /* flip_face.rs:5-29          1 child                                */
     RTG_TRANSLATE       = 7,  /* transform.rs:9-55          f = offset xyz, 1 child                */
-    RTG_ROTATE_Y        = 8,  /* transform.rs:57-153        f = angle in degrees, 1 child          */
+    RTG_ROTATE_Y        = 8,  /* transform.rs:57-153        f = angle in degrees, 1 child; i[0] = 1: f[1], f[2] = sin, cos given */
     RTG_BVH             = 9,  /* bvh.rs:15-89               children = the slice handed to BvhNode::new */
     RTG_LIST            = 10, /* hittable_list.rs:7-76      children in insertion order            */
     RTG_CONSTANT_MEDIUM = 11, /* constant_medium.rs:13-95   f = density, 1 child (boundary); material = Isotropic */

@@ -647,9 +647,10 @@ struct RotateY : Hittable {  // :57-153
     const Hittable *obj;
     Real sin_theta, cos_theta;
     Aabb bbox;
-    bool init(const Hittable *o, Real angle) {  // :65-108
+    bool init(const Hittable *o, Real angle, const Real *given_sincos = nullptr) {  // :65-108
         obj = o;
-        m_sincos(degrees_to_radians(angle), &sin_theta, &cos_theta);
+        if (given_sincos) { sin_theta = given_sincos[0]; cos_theta = given_sincos[1]; }
+        else m_sincos(degrees_to_radians(angle), &sin_theta, &cos_theta);
         Aabb b;
         if (!obj->bounding_box(0.0f, 1.0f, &b)) return false;
         Real mn[3] = {F32_MAX, F32_MAX, F32_MAX}, mx[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
@@ -1236,7 +1237,7 @@ struct orc_scene {
             const Hittable *c = build(ch[0], number, depth + 1);
             if (!c) return nullptr;
             RotateY *r = own(new RotateY());
-            if (!r->init(c, n.f[0])) { err = "Object does not have a bounding box ..."; return nullptr; }
+            if (!r->init(c, n.f[0], n.i[0] == 1 ? &n.f[1] : nullptr)) { err = "Object does not have a bounding box ..."; return nullptr; }
             res = r;
             break;
         }

@@ -173,7 +173,7 @@ HOST_SYMBOLS = [
     "rth_sampler_new", "rth_sampler_free", "rth_sampler_desc", "rth_flatten", "rth_flat_free", "rth_flat_desc",
     "rth_work_blocks", "rth_mat4_mul", "rth_mat4_invert", "rth_add_transform", "rth_add_cylinder", "rth_add_cone",
     "rth_add_paraboloid", "rth_add_hyperboloid", "rth_flatten_opts", "rth_write_png_rgb8", "rth_checkpoint_save",
-    "rth_checkpoint_load", "rth_image_decode", "rth_image_decode_file", "rth_image_free",
+    "rth_checkpoint_load", "rth_image_decode", "rth_image_decode_file", "rth_image_free", "rth_add_rotate_y_sincos",
 ]
 
 HIP_SYMBOLS = [
@@ -222,11 +222,12 @@ def host_lib():
     L.rth_add_flip_face.argtypes = [vp, i32]
     L.rth_add_translate.argtypes = [vp, i32, f3]
     L.rth_add_rotate_y.argtypes = [vp, i32, f]
+    L.rth_add_rotate_y_sincos.argtypes = [vp, i32, f, f]
     L.rth_add_bvh.argtypes = [vp, C.POINTER(i32), i32]
     L.rth_add_list.argtypes = [vp, C.POINTER(i32), i32]
     L.rth_add_constant_medium.argtypes = [vp, i32, i32, f]
     L.rth_add_triangle_mesh.argtypes = [vp, C.POINTER(rtg_vertex), u32, c_u32_p, u32, C.POINTER(rtg_mesh_node), u32,
-                                        C.c_float * 16, i32]
+                                        C.POINTER(C.c_float * 16), i32]
     L.rth_add_transform.argtypes = [vp, i32, C.c_float * 16]
     L.rth_add_cylinder.argtypes = [vp, f, f, f, f, i32]
     L.rth_add_cone.argtypes = [vp, f, f, f, i32]

@@ -194,8 +194,8 @@ int rt_group_create(const int *device_ids, int n, rt_group **out) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < i; ++j)
             if (device_ids[i] == device_ids[j]) return ctx_fail(nullptr, RT_E_INVALID, "rt_group_create: device %d listed twice", device_ids[i]);
-    const Rccl *R = rccl();
-    if (!R) return ctx_fail(nullptr, RT_E_RCCL, "%s", rccl_unavailable());
+    const Rccl *R = n > 1 ? rccl() : nullptr;          // a group of one needs no communicator: it works without RCCL
+    if (n > 1 && !R) return ctx_fail(nullptr, RT_E_RCCL, "%s", rccl_unavailable());
     rt_group *g = new (std::nothrow) rt_group();
     if (!g) return ctx_fail(nullptr, RT_E_OOM, "out of host memory");
     for (int i = 0; i < n; ++i) {
@@ -205,7 +205,7 @@ int rt_group_create(const int *device_ids, int n, rt_group **out) {
         g->ctxs.push_back(ctx);
     }
     g->comms.assign((size_t)n, nullptr);
-    ncclResult_t r = R->CommInitAll(g->comms.data(), n, device_ids);
+    ncclResult_t r = n > 1 ? R->CommInitAll(g->comms.data(), n, device_ids) : ncclSuccess;
     if (r != ncclSuccess) {
         g->comms.clear();
         rt_group_destroy(g);
@@ -226,7 +226,7 @@ int rt_group_reduce_to_root(rt_group *g, float *const *rgba_sums, int64_t n_floa
     if (!rgba_sums || n_floats < 0 || root < 0 || root >= n) return ctx_fail(c0, RT_E_INVALID, "rt_group_reduce_to_root: bad arguments (root %d of %d)", root, n);
     for (int i = 0; i < n; ++i)
         if (!rgba_sums[i]) return ctx_fail(c0, RT_E_INVALID, "rt_group_reduce_to_root: buffer %d is NULL", i);
-    if (n_floats == 0) return RT_OK;
+    if (n_floats == 0 || n == 1) return RT_OK;         // one device: its buffer is the sum
     const Rccl *R = rccl();
     if (!R) return ctx_fail(c0, RT_E_RCCL, "%s", rccl_unavailable());
     // one process drives all devices: the n calls of the one collective go between GroupStart / GroupEnd

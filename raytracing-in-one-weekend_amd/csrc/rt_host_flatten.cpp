@@ -253,8 +253,11 @@ struct Flattener {
         case RTG_ROTATE_Y: {
             if (n.child_count != 1) return fail("RotateY needs one child");
             if (w.has_rot || w.matrix >= 0) return fail("unsupported wrapper nesting: RotateY under RotateY/Transform");
-            float rads = (n.f[0] * 3.14159265358979323846f) / 180.0f;  // types.rs:44-46
-            pm::sincosf_(rads, &w.sin_t, &w.cos_t);
+            if (n.i[0] == 1) { w.sin_t = n.f[1]; w.cos_t = n.f[2]; }   // rth_add_rotate_y_sincos: the host's own values
+            else {
+                float rads = (n.f[0] * 3.14159265358979323846f) / 180.0f;  // types.rs:44-46
+                pm::sincosf_(rads, &w.sin_t, &w.cos_t);
+            }
             w.has_rot = true;
             return walk(ch[0], w, depth + 1);
         }

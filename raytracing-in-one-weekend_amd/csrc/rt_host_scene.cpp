@@ -394,6 +394,13 @@ static int wrapper(rth_scene *s, int type, int child, const float *f, int nf) {
 int rth_add_flip_face(rth_scene *s, int child) { return wrapper(s, RTG_FLIP_FACE, child, nullptr, 0); }
 int rth_add_translate(rth_scene *s, int child, const float offset[3]) { return wrapper(s, RTG_TRANSLATE, child, offset, 3); }
 int rth_add_rotate_y(rth_scene *s, int child, float degrees) { return wrapper(s, RTG_ROTATE_Y, child, &degrees, 1); }
+// A RotateY as the reference holds it (transform.rs:57-62): sin and cos as the host computed them, not the angle
+int rth_add_rotate_y_sincos(rth_scene *s, int child, float sin_theta, float cos_theta) {
+    const float f[3] = {0.0f, sin_theta, cos_theta};
+    int n = wrapper(s, RTG_ROTATE_Y, child, f, 3);
+    if (n >= 0) s->nodes[n].i[0] = 1;
+    return n;
+}
 
 int rth_add_transform(rth_scene *s, int child, const float obj2world[16]) {
     if (!obj2world) { set_error("transform: null matrix"); return RT_E_INVALID; }
@@ -466,8 +473,8 @@ int rth_add_triangle_mesh(rth_scene *s, const rtg_vertex *verts, uint32_t n_vert
     if (!verts || !indices || n_indices % 3 != 0) { set_error("mesh: bad arrays"); return RT_E_INVALID; }
     for (uint32_t i = 0; i < n_indices; ++i)
         if (indices[i] >= n_verts) { set_error("mesh: index %u out of range", indices[i]); return RT_E_INVALID; }
-    M4 o2w;
-    memcpy(o2w.a, obj2world, sizeof o2w.a);
+    M4 o2w = m4_identity();
+    if (obj2world) memcpy(o2w.a, obj2world, sizeof o2w.a);
     M4 w2o;
     if (!m4_invert(o2w, &w2o)) { set_error("mesh: obj2world is not invertible"); return RT_E_INVALID; }
     M4 n2w = m4_transpose(w2o);  // triangle_mesh.rs:49
@@ -475,6 +482,7 @@ int rth_add_triangle_mesh(rth_scene *s, const rtg_vertex *verts, uint32_t n_vert
     mesh->verts.resize(n_verts);
     for (uint32_t i = 0; i < n_verts; ++i) {
         const rtg_vertex &v = verts[i];
+        if (!obj2world) { mesh->verts[i] = v; continue; }   // already baked: TriangleMesh::vertices as the reference keeps them
         V3 p = m4_transform_point(o2w, v3(v.pos[0], v.pos[1], v.pos[2]));
         V3 nn = normalize(m4_transform_vector(n2w, v3(v.normal[0], v.normal[1], v.normal[2])));
         rtg_vertex o = v;

@@ -261,6 +261,9 @@ class Scene:
     def flip_face(self, child): return _check(_ffi.host_lib().rth_add_flip_face(self._h, child))
     def translate(self, child, offset): return _check(_ffi.host_lib().rth_add_translate(self._h, child, _f3(offset)))
     def rotate_y(self, child, degrees): return _check(_ffi.host_lib().rth_add_rotate_y(self._h, child, degrees))
+    def rotate_y_sincos(self, child, sin_theta, cos_theta):
+        """RotateY with the sin / cos its owner already holds (transform.rs:57-62)."""
+        return _check(_ffi.host_lib().rth_add_rotate_y_sincos(self._h, child, sin_theta, cos_theta))
     def transform(self, child, obj2world):
         """Transform::new(obj2world, child) (transform.rs:162-175); obj2world = 4x4 row-major, affine."""
         m = (C.c_float * 16)(*[float(x) for x in np.asarray(obj2world, np.float32).reshape(16)])
@@ -284,7 +287,8 @@ class Scene:
         verts = np.ascontiguousarray(verts, np.float32)
         indices = np.ascontiguousarray(indices, np.uint32)
         nodes = np.ascontiguousarray(nodes, np.uint32)
-        m = (C.c_float * 16)(*[float(x) for x in np.asarray(obj2world, np.float32).reshape(16)])
+        # obj2world None: the vertices are world-space already (TriangleMesh::vertices after triangle_mesh.rs:53-72)
+        m = None if obj2world is None else C.byref((C.c_float * 16)(*[float(x) for x in np.asarray(obj2world, np.float32).reshape(16)]))
         return _check(_ffi.host_lib().rth_add_triangle_mesh(
             self._h, C.cast(verts.ctypes.data, C.POINTER(_ffi.rtg_vertex)), verts.shape[0],
             indices.ctypes.data_as(_ffi.c_u32_p), indices.shape[0],

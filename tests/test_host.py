@@ -288,6 +288,36 @@ def test_unsupported_nesting_is_reported(rt):
         s.flatten()
 
 
+def test_constructors_that_take_what_the_reference_objects_hold(rt):
+    """integration/flatten.rs hands over RotateY's stored sin / cos (transform.rs:57-62) and TriangleMesh's baked vertices
+    (triangle_mesh.rs:53-72): both forms flatten to the same slots and tree as the constructor-argument forms."""
+    verts = np.array([[0, 0, 5, 0, 0, -2, 0, 0], [1, 0, 5, 0, 0, -2, 1, 0], [0, 1, 5, 0, 0, -2, 0, 1]], np.float32)
+    o2w = np.eye(4, dtype=np.float32); o2w[:3, 3] = (3, 4, 5); o2w[0, 0] = 2
+    tri, node = np.arange(3, dtype=np.uint32), np.array([[0, 3]], np.uint32)
+
+    def build(sincos=None, baked=None):
+        s = rt.host.Scene()
+        m = s.lambertian(s.solid(1, 1, 1))
+        blk = s.block((0, 0, 0), (1, 2, 1), m)
+        rot = s.rotate_y_sincos(blk, *sincos) if sincos else s.rotate_y(blk, 15.0)
+        mesh = s.triangle_mesh(baked, tri, node, None, m) if baked is not None else s.triangle_mesh(verts, tri, node, o2w, m)
+        s.set_roots(s.hittable_list([s.translate(rot, (1, 0, 2)), mesh]), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
+        return s
+
+    first = build()
+    flat = first.flatten()
+    g = first.graph().contents
+    baked = np.ctypeslib.as_array(C.cast(g.meshes[0].vertices, C.POINTER(C.c_float)), (3, 8)).copy()
+    assert baked[0, 0] == 3.0 and baked[1, 0] == 5.0 and abs(np.linalg.norm(baked[0, 3:6]) - 1) < 1e-6      # baked + normalised
+    xf = np.ctypeslib.as_array(flat.desc.xforms, (flat.desc.n_xforms, 8)).copy()
+    sin_t, cos_t = float(xf[0, 1]), float(xf[0, 2])
+    assert abs(sin_t - np.sin(np.deg2rad(15.0))) < 1e-6 and abs(cos_t - np.cos(np.deg2rad(15.0))) < 1e-6
+    second = build((sin_t, cos_t), baked)
+    other = second.flatten()
+    assert np.array_equal(other.slots().view(np.uint32), flat.slots().view(np.uint32))
+    assert np.array_equal(other.nodes().view(np.uint32), flat.nodes().view(np.uint32))
+
+
 def read_glb_positions(path):
     d = open(path, "rb").read()
     jlen = struct.unpack("<I", d[12:16])[0]
