@@ -324,10 +324,9 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             w.spp_batch = spp_batch;
             w.sample0 = (uint32_t)(a.spp_begin + s0);
             magic_div(spp_batch, &w.spp_m, &w.spp_k);
-            // pipe q renders tiles [t0, t1): whole tiles, so an item's index is the same with any number of pipes
-            const uint32_t t0 = (uint32_t)((uint64_t)n_tiles * q / n_pipes), t1 = (uint32_t)((uint64_t)n_tiles * (q + 1) / n_pipes);
-            w.item0 = t0 * spp_batch * 64u;
-            w.n_items = (t1 - t0) * spp_batch * 64u;
+            // pipe q renders the tiles t with t % n_pipes == q: whole tiles, so an item's index is the same with any number of pipes
+            w.pipe = (uint32_t)q; w.n_pipes = (uint32_t)n_pipes;
+            w.n_items = ((n_tiles - (uint32_t)q + (uint32_t)n_pipes - 1u) / (uint32_t)n_pipes) * spp_batch * 64u;
             const size_t items_up = ((size_t)w.n_items + shard_q - 1) / shard_q * shard_q;
             w.pool = (uint32_t)(items_up < ctx->wf_pool_entries ? items_up : ctx->wf_pool_entries);
             if (w.pool > pool_want) w.pool = (uint32_t)pool_want;

@@ -35,7 +35,7 @@ namespace rtk {
 #define RT_F32_MAX 3.40282347e+38f
 // traversal: run a leaf step once RT_LEAF_MIN lanes stand on a leaf (or nobody is on an inner node)
 #ifndef RT_LEAF_MIN
-#define RT_LEAF_MIN 16
+#define RT_LEAF_MIN 20
 #endif
 
 struct V3 {
@@ -116,7 +116,8 @@ struct Counters {  // only live in the STATS instantiation
 #endif
 constexpr bool kTimers = RT_REGION_TIMERS != 0;
 enum { RG_LOAD = 0, RG_FINISH, RG_RECORD, RG_TEXTURE, RG_EMIT, RG_METAL, RG_DIEL, RG_ISO, RG_LAMBERT, RG_L_LIGHTS, RG_L_COSINE,
-       RG_L_PDF, RG_B_MEDIA, RG_B_RECTS, RG_B_ALWAYS, RG_B_REST, RG_STORE, RG_NODE, RG_LEAF, RG_FETCH, RG_CAMERA, RG_SHADE_ALL, RG_BEGIN_ALL };
+       RG_L_PDF, RG_B_MEDIA, RG_B_RECTS, RG_B_ALWAYS, RG_B_REST, RG_STORE, RG_NODE, RG_LEAF, RG_FETCH, RG_CAMERA, RG_SHADE_ALL, RG_BEGIN_ALL,
+       RG_TRAV_ALL };
 #define RG_BEGIN(k) unsigned long long rg_t_##k = (kTimers && !STATS) ? __builtin_readcyclecounter() : 0ull
 #define RG_END(k)                                                                                              \
     do {                                                                                                       \
@@ -546,6 +547,18 @@ RT_DEV void consider(Hit &best, float t, int32_t id, int32_t slot) {
     if (t < best.t || (t == best.t && id > best.id)) { best.t = t; best.id = id; best.slot = slot; }
 }
 
+// 1 / d for the box tests only.  A component below 1e-30 in magnitude is replaced by 1e-30, so the reciprocal stays finite
+// and lo*inv - o*inv cannot turn into inf - inf; the reciprocal is the hardware estimate (v_rcp_f32, 1 ulp) instead of three
+// IEEE divisions of ~10 instructions each: a relative error of 1.2e-7 in a box's ray parameters is three orders of magnitude
+// below the padding of the boxes (1e-4 x max(1, |coords|)) for any ray that starts within ~800 scene extents of the box.
+// Nothing the reference computes goes through it: the primitive tests use the ray itself.
+RT_DEV V3 box_inv(V3 d) {
+    const float dx = fabsf(d.x) < 1.0e-30f ? 1.0e-30f : d.x;
+    const float dy = fabsf(d.y) < 1.0e-30f ? 1.0e-30f : d.y;
+    const float dz = fabsf(d.z) < 1.0e-30f ? 1.0e-30f : d.z;
+    return v3(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
+}
+
 // Slab test in the traversal's own arithmetic (boxes are padded by the flattener, so this need
 // not follow aabb3.rs): t = lo*inv - o*inv as one fma; `inv` is finite (see traverse()).
 RT_DEV bool slab(V3 lo, V3 hi, V3 inv, V3 oi, float t_min, float t_max, float *t_near) {
@@ -563,9 +576,13 @@ RT_DEV bool slab(V3 lo, V3 hi, V3 inv, V3 oi, float t_min, float t_max, float *t
 // [depth][block] array, so a wave's accesses hit 64 different banks), deeper ones in an HBM overflow area.
 // Entries carry no entry distance: LDS bytes per wave decide how many waves a CU holds, and the walk is
 // latency-bound; a stale entry costs one node visit (both child boxes then fail against best.t).
+// (The LDS pointer carries its address space in the type: a pointer that may be either LDS or global becomes a flat_load,
+// which goes down both memory paths; typed, a pop from the LDS part is a ds_read_b32.)
+#define RT_LDS __attribute__((address_space(3)))
 typedef uint32_t StackEntry;
+typedef RT_LDS StackEntry *LdsStackPtr;
 struct Stack {
-    StackEntry *lds;  uint32_t stride;
+    LdsStackPtr lds;  uint32_t stride;
     uint32_t lds_depth;
     StackEntry *ovf;  uint32_t ovf_stride;   // unused (null) when lds_depth covers the BVH depth
 };
@@ -584,6 +601,11 @@ RT_DEV int32_t pop_ref(const Stack &st, uint32_t &sp) {
 // nearest hit child is returned, the other hit children are pushed farthest first (so the nearer one is popped
 // first); with no hit the next stack entry is returned.  The order only decides how soon best_t shrinks: the
 // closest hit and its tie-break do not depend on it.
+// The walk is bound by VALU issue (PMC: 70-80 % of the issue slots on C1 / C3), so the visit is written for instruction
+// count: the plane a ray enters a box through on an axis follows from the sign of its direction there (sx = scale * inv < 0:
+// the parameter fma(q, sx, ox) falls as q grows, so it is the upper plane; the rounding of an fma is monotone, so this is
+// the min / max of the two parameters exactly) — six selects per node instead of six min / max per child; (key, ref) pairs
+// go through the sorting network together, so no child ref is looked up by index afterwards.
 template <bool STATS>
 RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t_min, float best_t, const Stack &stack, uint32_t &sp, Counters &cnt) {
     const float4 *n = sc.nodes + 4 * (size_t)ref;
@@ -593,34 +615,33 @@ RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t
     const float ox = __builtin_fmaf(n0.x, inv.x, -oi.x), oy = __builtin_fmaf(n0.y, inv.y, -oi.y), oz = __builtin_fmaf(n0.z, inv.z, -oi.z);
     const uint32_t qlx = __float_as_uint(n1.z), qhx = __float_as_uint(n1.w), qly = __float_as_uint(n2.x), qhy = __float_as_uint(n2.y),
                    qlz = __float_as_uint(n2.z), qhz = __float_as_uint(n2.w);
-    const int32_t refs[4] = {f2i(rf.x), f2i(rf.y), f2i(rf.z), f2i(rf.w)};
-    // sort key: entry distance with the child index in its two lowest bits (distances are >= t_min > 0 in the
-    // renderer, so their bit patterns order like unsigned integers); a miss sorts last
+    const bool bx = inv.x < 0.0f, by = inv.y < 0.0f, bz = inv.z < 0.0f;
+    const uint32_t qnx = bx ? qhx : qlx, qfx = bx ? qlx : qhx, qny = by ? qhy : qly, qfy = by ? qly : qhy, qnz = bz ? qhz : qlz, qfz = bz ? qlz : qhz;
+    int32_t rr[4] = {f2i(rf.x), f2i(rf.y), f2i(rf.z), f2i(rf.w)};
+    // sort key: entry distance (distances are >= t_min > 0 in the renderer, so their bit patterns order like unsigned
+    // integers); a miss sorts last
     uint32_t key[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int sh = 8 * c;
-        const float tx0 = __builtin_fmaf((float)((qlx >> sh) & 255u), sx, ox), tx1 = __builtin_fmaf((float)((qhx >> sh) & 255u), sx, ox);
-        const float ty0 = __builtin_fmaf((float)((qly >> sh) & 255u), sy, oy), ty1 = __builtin_fmaf((float)((qhy >> sh) & 255u), sy, oy);
-        const float tz0 = __builtin_fmaf((float)((qlz >> sh) & 255u), sz, oz), tz1 = __builtin_fmaf((float)((qhz >> sh) & 255u), sz, oz);
-        const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
-        const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), best_t));
-        const bool hit = tn <= tf * 1.0000004f && refs[c] != RT_BVH_EMPTY;
-        if (STATS && refs[c] != RT_BVH_EMPTY) cnt.box_tests += 1;
-        key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xffffffffu;
+        const float tnx = __builtin_fmaf((float)((qnx >> sh) & 255u), sx, ox), tfx = __builtin_fmaf((float)((qfx >> sh) & 255u), sx, ox);
+        const float tny = __builtin_fmaf((float)((qny >> sh) & 255u), sy, oy), tfy = __builtin_fmaf((float)((qfy >> sh) & 255u), sy, oy);
+        const float tnz = __builtin_fmaf((float)((qnz >> sh) & 255u), sz, oz), tfz = __builtin_fmaf((float)((qfz >> sh) & 255u), sz, oz);
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, t_min));
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best_t));
+        const bool hit = tn <= tf * 1.0000004f && rr[c] != RT_BVH_EMPTY;
+        if (STATS && rr[c] != RT_BVH_EMPTY) cnt.box_tests += 1;
+        key[c] = hit ? __float_as_uint(tn) : 0xffffffffu;
     }
-#define RT_CSWAP(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
+#define RT_CSWAP(i, j) { const bool sw_ = key[j] < key[i]; const uint32_t ki_ = key[i], kj_ = key[j]; const int32_t ri_ = rr[i], rj_ = rr[j]; \
+                         key[i] = sw_ ? kj_ : ki_; key[j] = sw_ ? ki_ : kj_; rr[i] = sw_ ? rj_ : ri_; rr[j] = sw_ ? ri_ : rj_; }
     RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
     if (key[0] == 0xffffffffu) return pop_ref(stack, sp);
 #pragma unroll
     for (int j = 3; j >= 1; --j)
-        if (key[j] != 0xffffffffu) {
-            const uint32_t c = key[j] & 3u;
-            stack_push(stack, sp, c == 0u ? refs[0] : c == 1u ? refs[1] : c == 2u ? refs[2] : refs[3]);
-        }
-    const uint32_t c0 = key[0] & 3u;
-    return c0 == 0u ? refs[0] : c0 == 1u ? refs[1] : c0 == 2u ? refs[2] : refs[3];
+        if (key[j] != 0xffffffffu) stack_push(stack, sp, rr[j]);
+    return rr[0];
 }
 
 // "while-while" traversal: every lane walks inner nodes until it stands on a leaf (or is done);
@@ -630,12 +651,7 @@ template <bool STATS>
 RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_id, Hit &best, const Stack &stack, Counters &cnt) {
     int32_t ref = sc.root_ref;
     if (ref == RT_BVH_EMPTY) return;
-    // For the box tests only, a direction component below 1e-30 in magnitude is replaced by 1e-30:
-    // 1/d stays finite, so lo*inv - o*inv cannot turn into inf - inf and the slab keeps its sign.
-    float dx = fabsf(r.d.x) < 1.0e-30f ? 1.0e-30f : r.d.x;
-    float dy = fabsf(r.d.y) < 1.0e-30f ? 1.0e-30f : r.d.y;
-    float dz = fabsf(r.d.z) < 1.0e-30f ? 1.0e-30f : r.d.z;
-    V3 inv = v3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+    V3 inv = box_inv(r.d);
     V3 oi = r.o * inv;
     uint32_t sp = 0;
     for (;;) {
@@ -983,10 +999,7 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
     for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m)
         if ((EXT & EXT_MEDIA) && med_ok[m] && f2i(sc.media[2 * m + 1].z) > tv.floor_id) consider(tv.best, med_t[m], f2i(sc.media[2 * m + 1].z), -(int32_t)(m + 1));
     if (sc.root_ref == RT_BVH_EMPTY) return false;
-    float dx = fabsf(r.d.x) < 1.0e-30f ? 1.0e-30f : r.d.x;
-    float dy = fabsf(r.d.y) < 1.0e-30f ? 1.0e-30f : r.d.y;
-    float dz = fabsf(r.d.z) < 1.0e-30f ? 1.0e-30f : r.d.z;
-    tv.inv = v3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+    tv.inv = box_inv(r.d);
     tv.oi = r.o * tv.inv;
     tv.ref = sc.root_ref;
     return true;
@@ -1008,6 +1021,18 @@ RT_DEV void trav_leaf_step(const DScene &sc, const Ray &r, float t_min, Trav &tv
         if (slot_hit<STATS, EXT>(sc, first + i, r, t_min, tv.best.t, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)(first + i));
     }
     tv.ref = pop_ref(stack, tv.sp);
+}
+
+// The primitive tests of one leaf, for a walk that keeps the leaf aside and goes on (wf_traverse_kernel): no pop.
+template <bool STATS, int EXT>
+RT_DEV void trav_leaf_test(const DScene &sc, const Ray &r, float t_min, Trav &tv, int32_t leaf_ref, Counters &cnt) {
+    uint32_t code = (uint32_t)~leaf_ref;
+    uint32_t first = code >> 3, count = (code & 7u) + 1u;
+    for (uint32_t i = 0; i < count; ++i) {
+        float t;
+        int32_t id;
+        if (slot_hit<STATS, EXT>(sc, first + i, r, t_min, tv.best.t, &t, &id, cnt) && id > tv.floor_id) consider(tv.best, t, id, (int32_t)(first + i));
+    }
 }
 
 // After the walk: if nothing came after the last NaN candidate, that candidate is the hit.
@@ -1473,7 +1498,7 @@ __global__ void __launch_bounds__(256) first_hit_kernel(DScene sc, const float *
     Counters cnt{};
     rts::Rng rng{0, 1};
     Hit best;
-    const Stack stack{lds_stack + threadIdx.x, blockDim.x, lds_depth, ovf ? ovf + i : nullptr, ovf_stride};   // ovf == null: the whole stack fits LDS
+    const Stack stack{(LdsStackPtr)lds_stack + threadIdx.x, blockDim.x, lds_depth, ovf ? ovf + i : nullptr, ovf_stride};   // ovf == null: the whole stack fits LDS
     bool h = closest_hit<false>(sc, r, t_min, t_max, false, rng, best, stack, cnt);
     Rec rec{};
     if (h) rec = slot_record(sc, (uint32_t)best.slot, r, best.t, true, t_min, t_max);

@@ -62,8 +62,9 @@ struct WfArgs {
     RenderArgs a;
     uint32_t pool;        // entries per pool buffer = RT_WF_SHARDS * cap
     uint32_t cap;         // entries per shard (multiple of 256)
-    uint32_t item0;       // first item of this pipeline (items are numbered over the whole batch)
-    uint32_t n_items;     // items of this pipeline in this batch (all: n_tiles * spp_batch * 64)
+    uint32_t pipe, n_pipes;   // this pipeline renders the tiles t with t % n_pipes == pipe (interleaved: the pipelines then carry
+                          // the same mix of cheap and expensive pixels and drain together; top / bottom halves did not)
+    uint32_t n_items;     // items of this pipeline in this batch (its tiles * spp_batch * 64)
     uint32_t spp_batch;   // samples per pixel in this batch
     uint32_t sample0;     // absolute index of the batch's first sample
     uint32_t tiles_x, n_tiles;   // 8x8 pixel tiles over the window
@@ -191,7 +192,11 @@ __global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScen
     const uint32_t off = off0 + threadIdx.x;
     const bool mine = off >= n_surv && off < n_surv + n_new;
     Counters cnt{};
-    const uint32_t g = w.item0 + item_head + room_before + (off - n_surv), e = j;
+    // the pipeline's li-th item = sample k of its lt-th tile; items are numbered over the whole batch (tile-major), as the
+    // sample buffer and the fold index them
+    const uint32_t li = item_head + room_before + (off - n_surv), lg = li >> 6;
+    const uint32_t lt = div_magic(lg, w.spp_m, w.spp_k), lk = lg - lt * w.spp_batch;
+    const uint32_t g = (((lt * w.n_pipes + w.pipe) * w.spp_batch + lk) << 6) | (li & 63u), e = j;
     WfPath p;
     int x, y;
     const bool inside = mine && item_pixel(w, g, &x, &y, &p.sample);
@@ -233,16 +238,22 @@ __global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScen
 #define RT_WF_SORT 1           // shade: deal a block's entries to its threads in material order
 #endif
 #ifndef RT_WF_FETCH_MIN
-#define RT_WF_FETCH_MIN 20     // refill when at least this many lanes of the wave are idle
+#define RT_WF_FETCH_MIN 12     // refill when at least this many lanes of the wave are idle
+#endif
+#ifndef RT_WF_NODE_STEPS
+#define RT_WF_NODE_STEPS 3     // node steps per turn of the traverse loop
 #endif
 #ifndef RT_WF_CHUNK
 #define RT_WF_CHUNK 64u        // entries a wave takes from its shard's cursor at a time
 #endif
 
 // Persistent waves.  A lane holds one ray; when RT_WF_FETCH_MIN lanes have finished theirs the wave
-// takes the next entries of the pool for them, so the node loop runs with most lanes busy.  Inside,
-// "while-while": node steps for everyone standing on an inner node, leaf steps once enough lanes
-// stand on a leaf (RT_LEAF_MIN) or nobody is left on an inner node.
+// takes the next entries of the pool for them, so the node loop runs with most lanes busy.
+// Inside, node steps and leaf steps are decoupled: a lane that reaches a leaf puts it aside (`pend`) and goes on
+// with the next entry of its stack; the wave runs the primitive tests once RT_LEAF_MIN lanes hold a leaf (or nobody
+// can take a node step).  A lane that reaches a second leaf before that waits.  Testing a leaf later than a
+// depth-first walk would only means that best.t shrinks later (a few more node visits); the closest hit and its
+// tie-break do not depend on the order of the tests.
 #ifndef RT_WF_TRAV_WAVES
 #define RT_WF_TRAV_WAVES 6      // min waves per SIMD the traverse kernel is compiled for (80 VGPRs, no spills)
 #endif
@@ -251,7 +262,7 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
                                                           StackEntry *ovf, unsigned long long *stats) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const Stack stack{lds_stack + tid, blockDim.x, lds_depth, ovf ? ovf + (size_t)blockIdx.x * blockDim.x + tid : nullptr, gridDim.x * blockDim.x};
+    const Stack stack{(LdsStackPtr)lds_stack + tid, 256u, lds_depth, ovf ? ovf + (size_t)blockIdx.x * 256u + tid : nullptr, gridDim.x * 256u};
     const uint32_t shard = blockIdx.x % RT_WF_SHARDS;
     WfShard *c = &ctr[it % RT_WF_RING].sh[shard];
     const uint32_t n = c->count_in, shard_base = shard * cap;
@@ -259,12 +270,14 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
     uint32_t w_next = 0, w_end = 0;
     bool exhausted = n == 0;
     int32_t idx = -1;
+    int32_t pend = RT_BVH_EMPTY;      // a leaf put aside (< 0), or RT_BVH_EMPTY
     Ray r;
     r.o = v3(0.0f, 0.0f, 0.0f); r.d = r.o; r.time = 0.0f;
     Trav tv;
     tv.ref = RT_BVH_EMPTY; tv.sp = 0; tv.best.t = 0.0f; tv.best.id = -1; tv.best.slot = 0; tv.floor_id = -1;
     tv.inv = r.o; tv.oi = r.o;
     const float T_MIN = 0.001f;
+    RG_BEGIN(RG_TRAV_ALL);
     for (;;) {
         const unsigned long long m_idle = __ballot(idx < 0);
         const uint32_t n_idle = (uint32_t)__popcll(m_idle);
@@ -291,11 +304,7 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
                         idx = (int32_t)i;
                         r.o = v3(o.x, o.y, o.z); r.d = v3(d.x, d.y, d.z); r.time = o.w;
                         tv.best.t = h.x; tv.best.id = f2i(h.y); tv.best.slot = f2i(h.z); tv.floor_id = f2i(h.w);
-                        // the same box-test arithmetic as begin_trace()
-                        float dx = fabsf(r.d.x) < 1.0e-30f ? 1.0e-30f : r.d.x;
-                        float dy = fabsf(r.d.y) < 1.0e-30f ? 1.0e-30f : r.d.y;
-                        float dz = fabsf(r.d.z) < 1.0e-30f ? 1.0e-30f : r.d.z;
-                        tv.inv = v3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+                        tv.inv = box_inv(r.d);
                         tv.oi = r.o * tv.inv;
                         tv.sp = 0;
                         tv.ref = sc.root_ref;
@@ -306,25 +315,32 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
             RG_END(RG_FETCH);
             if (__ballot(idx >= 0) == 0ull) continue;   // nothing to walk among what was fetched
         }
-        // node steps
-        phase_count<STATS>(cnt, PH_NODE, idx >= 0 && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
-        RG_BEGIN(RG_NODE);
-        if (idx >= 0 && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY) trav_node_step<STATS>(sc, T_MIN, tv, stack, cnt);
-        RG_END(RG_NODE);
-        const bool at_leaf = idx >= 0 && tv.ref < 0;
-        const unsigned long long m_leaf = __ballot(at_leaf);
+        // node steps (RT_WF_NODE_STEPS per turn of the loop: the ballots and the refill test above are paid once for them)
+#pragma unroll
+        for (int k = 0; k < RT_WF_NODE_STEPS; ++k) {
+            if (idx >= 0 && tv.ref < 0 && pend == RT_BVH_EMPTY) { pend = tv.ref; tv.ref = pop_ref(stack, tv.sp); }   // leaf aside, walk on
+            const bool on_node = idx >= 0 && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY;
+            phase_count<STATS>(cnt, PH_NODE, on_node);
+            RG_BEGIN(RG_NODE);
+            if (on_node) trav_node_step<STATS>(sc, T_MIN, tv, stack, cnt);
+            RG_END(RG_NODE);
+        }
+        if (idx >= 0 && tv.ref < 0 && pend == RT_BVH_EMPTY) { pend = tv.ref; tv.ref = pop_ref(stack, tv.sp); }
+        const bool has_leaf = idx >= 0 && pend != RT_BVH_EMPTY;
+        const unsigned long long m_leaf = __ballot(has_leaf);
         const unsigned long long m_node = __ballot(idx >= 0 && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
         if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
-            phase_count<STATS>(cnt, PH_LEAF, at_leaf);
+            phase_count<STATS>(cnt, PH_LEAF, has_leaf);
             RG_BEGIN(RG_LEAF);
-            if (at_leaf) trav_leaf_step<STATS, EXT>(sc, r, T_MIN, tv, stack, cnt);
+            if (has_leaf) { trav_leaf_test<STATS, EXT>(sc, r, T_MIN, tv, pend, cnt); pend = RT_BVH_EMPTY; }
             RG_END(RG_LEAF);
         }
-        if (idx >= 0 && tv.ref == RT_BVH_EMPTY) {
+        if (idx >= 0 && tv.ref == RT_BVH_EMPTY && pend == RT_BVH_EMPTY) {
             q.hit[idx] = make_float4(tv.best.t, __int_as_float(tv.best.id), __int_as_float(tv.best.slot), __int_as_float(tv.floor_id));
             idx = -1;
         }
     }
+    RG_END(RG_TRAV_ALL);
     if (STATS || kTimers) flush_counters<STATS>(cnt, 0u, stats);
 }
 
@@ -463,7 +479,7 @@ __global__ void __launch_bounds__(64) wf_tail_kernel(DScene sc, WfArgs w, PathQ 
     if (blockIdx.x == 0 && lane == 0) status[0] = 0u;   // what the next generate would report
     const uint32_t shard = blockIdx.x % RT_WF_SHARDS, b = blockIdx.x / RT_WF_SHARDS, nb = gridDim.x / RT_WF_SHARDS;
     const uint32_t n = c->sh[shard].count_in;
-    const Stack stack{lds_stack + lane, blockDim.x, lds_depth, ovf ? ovf + (size_t)blockIdx.x * blockDim.x + lane : nullptr, gridDim.x * blockDim.x};
+    const Stack stack{(LdsStackPtr)lds_stack + lane, blockDim.x, lds_depth, ovf ? ovf + (size_t)blockIdx.x * blockDim.x + lane : nullptr, gridDim.x * blockDim.x};
     const V3 background = v3(w.a.bg[0], w.a.bg[1], w.a.bg[2]);
     const float T_MIN = 0.001f;
     Counters cnt{};
@@ -496,10 +512,7 @@ __global__ void __launch_bounds__(64) wf_tail_kernel(DScene sc, WfArgs w, PathQ 
                 tv.best.t = h.x; tv.best.id = f2i(h.y); tv.best.slot = f2i(h.z); tv.floor_id = f2i(h.w);
                 if (walk) {     // as the traverse kernel starts a walk: the box-test arithmetic of begin_trace()
                     const Ray &r = p.ps.ray;
-                    float dx = fabsf(r.d.x) < 1.0e-30f ? 1.0e-30f : r.d.x;
-                    float dy = fabsf(r.d.y) < 1.0e-30f ? 1.0e-30f : r.d.y;
-                    float dz = fabsf(r.d.z) < 1.0e-30f ? 1.0e-30f : r.d.z;
-                    tv.inv = v3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+                    tv.inv = box_inv(r.d);
                     tv.oi = r.o * tv.inv;
                     tv.sp = 0;
                     tv.ref = sc.root_ref;

@@ -24,12 +24,14 @@ with tempfile.TemporaryFile() as f:
 line_ = [l for l in err.splitlines() if l.startswith("[rt-regions]")]
 if not line_: sys.exit("library was not built with -DRT_REGION_TIMERS=1:\n" + err[-2000:])
 st["region_cycles"] = [int(x) for x in line_[-1].split()[1:]]
-names = "LOAD FINISH RECORD TEXTURE EMIT METAL DIEL ISO LAMBERT L_LIGHTS L_COSINE L_PDF B_MEDIA B_RECTS B_ALWAYS B_REST STORE NODE LEAF FETCH CAMERA SHADE_ALL BEGIN_ALL".split()
+names = "LOAD FINISH RECORD TEXTURE EMIT METAL DIEL ISO LAMBERT L_LIGHTS L_COSINE L_PDF B_MEDIA B_RECTS B_ALWAYS B_REST STORE NODE LEAF FETCH CAMERA SHADE_ALL BEGIN_ALL TRAV_ALL".split()
 rc = dict(zip(names, st["region_cycles"]))
 rays = st["rays"]
-print(wl, "rays", rays, "paths", st["paths"])
-top_s = ["LOAD", "SHADE_ALL", "BEGIN_ALL", "STORE"]; top_t = ["FETCH", "NODE", "LEAF"]
-tot = sum(rc[k] for k in top_s + top_t + ["CAMERA"])
+print(wl, "rays", rays, "paths", st["paths"], "node visits/ray %.2f" % (st["node_visits"] / rays), "prim tests/ray %.2f" % (sum(st["prim_tests"]) / rays),
+      "occupancy node %.3f leaf %.3f" % (st["phase_lanes"][0] / max(1, st["phase_slots"][0]), st["phase_lanes"][1] / max(1, st["phase_slots"][1])),
+      "node steps/ray %.2f leaf steps/ray %.2f (wave-level, x64 lanes)" % (st["phase_slots"][0] / rays, st["phase_slots"][1] / rays))
+top_s = ["LOAD", "SHADE_ALL", "BEGIN_ALL", "STORE"]; top_t = ["TRAV_ALL", "FETCH", "NODE", "LEAF"]
+tot = sum(rc[k] for k in top_s + ["TRAV_ALL", "CAMERA"])
 def line(k, indent=""): print("%s%-10s %6.2f%%  %8.1f wave-cycles/ray" % (indent, k, 100.0 * rc[k] / tot, rc[k] / rays))
 print("-- shade kernel"); [line(k) for k in top_s]
 print("   inside shade_hit:"); [line(k, "   ") for k in ("RECORD", "EMIT", "METAL", "DIEL", "ISO", "LAMBERT")]
