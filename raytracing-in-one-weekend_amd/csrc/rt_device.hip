@@ -285,6 +285,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     if (tail_nb > trav_blocks / 16u) tail_nb = trav_blocks / 16u;        // its lanes share the pipeline's stack overflow area
     if (tail_nb < 1u) tail_nb = 1u;
     const size_t tail_lds = (size_t)lds_depth * 64 * sizeof(StackEntry);
+    const int tail_group = (int)env_size("RT_WF_TAIL_GROUP", 4, 1, 16);   // iterations enqueued at a time once every item is out
 
     struct Pipe {
         hipStream_t s;
@@ -296,6 +297,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         uint32_t it, groups;
         unsigned chunks;          // shade / generate grid: chunks of 256 entries per shard (x), 64 shards (y)
         unsigned trav_blocks;     // traverse grid (a multiple of the 64 shards)
+        uint32_t it_end;          // (once items_out) no path can be alive after this iteration
         bool items_out;           // the host has seen a status with every item handed out: the pool only shrinks from there
         bool drained;
     } pipe[kMaxPipes];
@@ -335,7 +337,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             P.items_out = false;
             P.trav_blocks = trav_blocks;
             HIP_TRY(ctx, hipMemsetAsync(P.ctr, 0, (RT_WF_RING + 1) * sizeof(WfCounters), P.s));
-            P.it = 0; P.groups = 0; P.drained = false;
+            P.it = 0; P.groups = 0; P.drained = false; P.it_end = 0xffffffffu;
             hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, w, P.Q[1], P.ctr, P.it,
                                ctx->wf_samples, P.d_status, d_stats, d_rays);
         }
@@ -351,7 +353,11 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                     if (hs[0] == 0u && hs[1] == P.w.n_items) { P.drained = true; --live; continue; }
                     if (p->cancel && *p->cancel) { (void)hipDeviceSynchronize(); return fail(ctx, RT_E_CANCELLED, "cancelled"); }
                     if (hs[3] != 0xffffffffu) {   // every item is out and the largest shard held hs[3] paths: the pool only shrinks from there,
-                        P.items_out = true;       // so the grids shrink with it (an empty iteration then costs a few microseconds, not 3 x 15)
+                        // so the grids shrink with it (an empty iteration then costs a few microseconds, not 3 x 15).  A path loses one
+                        // unit of depth per iteration, so max_depth iterations after this status (taken after iteration hs[2] - 1) the
+                        // pool is empty whatever the scene: the host may enqueue that far ahead without waste.
+                        if (!P.items_out) P.it_end = hs[2] + (uint32_t)(a.max_depth > 0 ? a.max_depth : 0) + 1u;
+                        P.items_out = true;
                         const unsigned need = (hs[3] + 255u) / 256u;
                         P.chunks = need < 1u ? 1u : (need < P.w.cap / 256u ? need : P.w.cap / 256u);
                         const unsigned tb = P.chunks * RT_WF_SHARDS;
@@ -360,7 +366,8 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                 }
                 // groups of 8 iterations while items are handed out; 4 in the tail, where what is enqueued after the pool has
                 // drained (the host learns of it a group late) is pure waste
-                for (int k = 0, gsize = P.items_out ? 4 : 8; k < gsize; ++k) {
+                for (int k = 0, gsize = P.items_out ? tail_group : 8; k < gsize; ++k) {
+                    if (P.items_out && P.it >= P.it_end) break;   // every path has run out of depth by then: nothing left to enqueue
                     const uint32_t it = ++P.it;
                     const PathQ &cur = P.Q[it & 1], &nxt = P.Q[(it + 1) & 1];
                     if (has_bvh) hipLaunchKernelGGL(trav_kernel, dim3(P.trav_blocks), dim3(256), lds, P.s, ctx->sc, cur, P.ctr, it, P.w.cap,
