@@ -158,6 +158,14 @@ void rth_flat_desc(const rth_flat *f, rt_scene_desc *out);
  * (math/src/mat4.rs:641-655).  Row-major 4x4.  rth_mat4_invert returns RT_E_INVALID for det == 0. */
 void rth_mat4_mul(const float a[16], const float b[16], float out[16]);
 int  rth_mat4_invert(const float m[16], float out[16]);
+/* math/src/mat4.rs:52-74, for the reference's own known answer (mat4.rs:657-667) */
+void rth_mat4_transpose(const float m[16], float out[16]);
+/* math/src/colors.rs, which feeds the palette colours of scene_blocks (main.rs:1031-1133, From<u32>): :34-41 ARGB -> f32 rgba,
+ * :24-26 u8 components -> ARGB, :230-262 "rrggbb" / "#aarrggbb" -> u8 r, g, b, a (all zero when it does not parse).  The
+ * reference's own known answers (colors.rs:589-629) are in tests/test_host.py. */
+void     rth_color_from_u32(uint32_t argb, float out_rgba[4]);
+uint32_t rth_rgba8_to_u32(uint8_t r, uint8_t g, uint8_t b, uint8_t a);
+void     rth_rgba8_from_html(const char *text, uint8_t out_rgba[4]);
 
 /* ------------------------------------------------------------------ output
  * The screenshot of main.rs:1543-1556 as an 8-bit RGB PNG (rgb = height * width * 3 bytes, row 0 = top; take them from

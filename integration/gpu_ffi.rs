@@ -311,6 +311,10 @@ extern "C" {
                              nodes: *mut *const rtg_mesh_node, n_nodes: *mut u32);
     pub fn rth_mat4_mul(a: *const f32, b: *const f32, out: *mut f32);
     pub fn rth_mat4_invert(m: *const f32, out: *mut f32) -> c_int;
+    pub fn rth_mat4_transpose(m: *const f32, out: *mut f32);
+    pub fn rth_color_from_u32(argb: u32, out_rgba: *mut f32);
+    pub fn rth_rgba8_to_u32(r: u8, g: u8, b: u8, a: u8) -> u32;
+    pub fn rth_rgba8_from_html(text: *const c_char, out_rgba: *mut u8);
     pub fn rth_work_blocks(width: i32, height: i32, block_pixels: i32, out_xyxy: *mut i32, cap: i32) -> i32;
     pub fn rth_image_decode(data: *const u8, size: usize, width: *mut i32, height: *mut i32, rgba: *mut *mut u8) -> c_int;
     pub fn rth_image_decode_file(path: *const c_char, width: *mut i32, height: *mut i32, rgba: *mut *mut u8) -> c_int;

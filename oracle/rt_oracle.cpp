@@ -108,9 +108,25 @@ inline void m_sincos(Real x, Real *s, Real *c) {
 
 const Real C_PI = 3.14159265358979323846f;
 inline Real degrees_to_radians(Real d) { return (d * C_PI) / 180.0f; }       // types.rs:44-46
-inline Real random_real() { return rts::random_real(*tl_rng); }                // types.rs:48-50
-inline Real random_real_range(Real lo, Real hi) { return rts::random_real_range(*tl_rng, lo, hi); }  // :52-55
-inline int random_int(int lo, int hi) { return rts::random_int(*tl_rng, lo, hi); }                    // :106-108
+// Known-answer hook (orc_bounce): a caller-supplied sequence of "random" numbers instead of the stream
+thread_local const float *tl_forced = nullptr;
+thread_local int tl_forced_left = 0, tl_forced_used = 0;
+inline Real random_real() {                                                     // types.rs:48-50
+    if (tl_forced) {
+        ++tl_forced_used;
+        if (tl_forced_left > 0) { --tl_forced_left; return *tl_forced++; }
+        return 0.0f;                                                            // (ran out: the caller sees used > given)
+    }
+    return rts::random_real(*tl_rng);
+}
+inline Real random_real_range(Real lo, Real hi) {                              // :52-55: rand's UniformFloat = u * (hi - lo) + lo
+    if (tl_forced) { Real u = random_real(), scale = hi - lo, v = u * scale; return v + lo; }
+    return rts::random_real_range(*tl_rng, lo, hi);
+}
+inline int random_int(int lo, int hi) {                                                               // :106-108
+    if (tl_forced) { int k = lo + (int)(random_real() * (Real)(hi - lo + 1)); return k > hi ? hi : k; }   // (hook: xi picks the object)
+    return rts::random_int(*tl_rng, lo, hi);
+}
 inline Vec3 rand_vec3_range(Real lo, Real hi) {                                 // types.rs:87-93
     Real x = random_real_range(lo, hi), y = random_real_range(lo, hi), z = random_real_range(lo, hi);
     return V(x, y, z);
@@ -1671,6 +1687,60 @@ float orc_math(int32_t fn, float a, float b, int32_t use_libm) {
 float orc_perlin(const rtg_perlin *table, const float p[3], int32_t depth) {
     PerlinNoise n{table};
     return depth > 0 ? n.turbulence(V(p[0], p[1], p[2]), depth) : n.noise(V(p[0], p[1], p[2]));
+}
+
+// Known-answer hook: ONE bounce of ray_color (camera.rs:264-308) for a given ray, with the random numbers of that bounce taken
+// from xi[0..n_xi) in the order the reference draws them (media in world order, then the material, then the mixture pdf).
+// out[0] kind: 0 miss, 1 no scatter (emitted only), 2 specular, 3 pdf;  out[1] prim id  out[2] t  out[3..5] p  out[6..8] normal
+// out[9] front_face  out[10..12] scattered direction  out[13..15] attenuation  out[16] mixture pdf value after the clamp of
+// camera.rs:279-288  out[17] scattering_pdf  out[18..20] emitted  out[21] numbers drawn.  Returns 0, or RT_E_INVALID.
+int orc_bounce(const orc_scene *s, const float ray7[7], const float *xi, int32_t n_xi, float out[22]) {
+    if (!s || !ray7 || !out || n_xi < 0) return RT_E_INVALID;
+    GlobalOptions go(s);
+    for (int i = 0; i < 22; ++i) out[i] = 0.0f;
+    static const float none = 0.0f;
+    tl_forced = xi ? xi : &none; tl_forced_left = xi ? n_xi : 0; tl_forced_used = 0;
+    Ray r{V(ray7[0], ray7[1], ray7[2]), V(ray7[3], ray7[4], ray7[5]), ray7[6]};
+    HitRecord rec;
+    auto done = [&]() { out[21] = (float)tl_forced_used; tl_forced = nullptr; tl_forced_left = 0; return RT_OK; };
+    if (!s->world->hit(r, 0.001f, INFINITY, &rec)) return done();
+    out[1] = (float)rec.prim_id; out[2] = rec.t;
+    out[3] = rec.p.x; out[4] = rec.p.y; out[5] = rec.p.z;
+    out[6] = rec.normal.x; out[7] = rec.normal.y; out[8] = rec.normal.z;
+    out[9] = rec.front_face ? 1.0f : 0.0f;
+    Color emitted = rec.mtl->emitted(r, rec, rec.u, rec.v, rec.p);
+    out[18] = emitted.r; out[19] = emitted.g; out[20] = emitted.b;
+    ScatterRecord scatter;
+    if (!rec.mtl->scatter(r, rec, &scatter)) { out[0] = 1.0f; return done(); }
+    out[13] = scatter.attenuation.r; out[14] = scatter.attenuation.g; out[15] = scatter.attenuation.b;
+    if (scatter.is_specular) {
+        out[0] = 2.0f;
+        out[10] = scatter.ray.direction.x; out[11] = scatter.ray.direction.y; out[12] = scatter.ray.direction.z;
+        return done();
+    }
+    out[0] = 3.0f;
+    HittablePdf light_pdf(s->lights, rec.p);
+    MixturePdf mixed_pdf(&light_pdf, scatter.pdf.get());
+    Ray scattered_ray{rec.p, mixed_pdf.generate(), r.time};
+    Real pdf_val = mixed_pdf.value(scattered_ray.direction);
+    if (std::fabs(pdf_val) < 1.0E-5f) pdf_val = std::signbit(pdf_val) ? -1.0E-4f : 1.0E-4f;
+    out[10] = scattered_ray.direction.x; out[11] = scattered_ray.direction.y; out[12] = scattered_ray.direction.z;
+    out[16] = pdf_val;
+    out[17] = rec.mtl->scattering_pdf(r, rec, scattered_ray);
+    return done();
+}
+
+// Known-answer hook for the oracle's own matrix code (math/src/mat4.rs): op 0 transpose (:52-74), 1 invert (:608-617; returns
+// RT_E_INVALID for det == 0), 2 adjoint (:567-606).  Row-major 4x4.
+int orc_mat4(int32_t op, const float in[16], float out[16]) {
+    Mat4 m{}, r{};
+    for (int i = 0; i < 16; ++i) m.a[i] = in[i];
+    if (op == 0) r = mat4_transpose(m);
+    else if (op == 1) { if (!mat4_invert(m, &r)) return RT_E_INVALID; }
+    else if (op == 2) r = mat4_adjoint(m);
+    else return RT_E_INVALID;
+    for (int i = 0; i < 16; ++i) out[i] = r.a[i];
+    return RT_OK;
 }
 
 float orc_lights_pdf_value(const orc_scene *s, const float o[3], const float v[3]) {

@@ -174,6 +174,7 @@ HOST_SYMBOLS = [
     "rth_work_blocks", "rth_mat4_mul", "rth_mat4_invert", "rth_add_transform", "rth_add_cylinder", "rth_add_cone",
     "rth_add_paraboloid", "rth_add_hyperboloid", "rth_flatten_opts", "rth_write_png_rgb8", "rth_checkpoint_save",
     "rth_checkpoint_load", "rth_image_decode", "rth_image_decode_file", "rth_image_free", "rth_add_rotate_y_sincos",
+    "rth_mat4_transpose", "rth_color_from_u32", "rth_rgba8_to_u32", "rth_rgba8_from_html",
 ]
 
 HIP_SYMBOLS = [

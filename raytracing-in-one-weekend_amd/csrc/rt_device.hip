@@ -399,6 +399,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         unsigned long long h[64];
         HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
+        fprintf(stderr, "[rt-turns] %llu\n", h[RT_STAT_WORDS]);
         fprintf(stderr, "[rt-regions]");
         for (int i = 0; i < RT_N_REGIONS; ++i) fprintf(stderr, " %llu", h[RT_STAT_WORDS + 1 + i]);
         fprintf(stderr, "\n");

@@ -9,6 +9,8 @@
 #include <sstream>
 
 #include "rt_host_internal.h"
+#include <cctype>
+#include <string>
 
 using namespace rth;
 
@@ -425,6 +427,56 @@ int rth_mat4_invert(const float m[16], float out[16]) {
     if (!m4_invert(x, &r)) { set_error("Matrix is not invertible"); return RT_E_INVALID; }
     memcpy(out, r.a, 64);
     return RT_OK;
+}
+
+void rth_mat4_transpose(const float m[16], float out[16]) {
+    M4 x;
+    memcpy(x.a, m, 64);
+    M4 r = m4_transpose(x);
+    memcpy(out, r.a, 64);
+}
+
+/* ------------------------------------------------------------------ colours (math/src/colors.rs) */
+
+// NumColorComponent::from_u32 for f32 (colors.rs:34-41): ARGB packed -> r, g, b, a in [0, 1]
+void rth_color_from_u32(uint32_t c, float out_rgba[4]) {
+    out_rgba[0] = (float)((c >> 16) & 0xFFu) / 255.0f;
+    out_rgba[1] = (float)((c >> 8) & 0xFFu) / 255.0f;
+    out_rgba[2] = (float)(c & 0xFFu) / 255.0f;
+    out_rgba[3] = (float)((c >> 24) & 0xFFu) / 255.0f;
+}
+
+// NumColorComponent::to_u32 for u8 (colors.rs:24-26)
+uint32_t rth_rgba8_to_u32(uint8_t r, uint8_t g, uint8_t b, uint8_t a) {
+    return ((uint32_t)a << 24) | ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;
+}
+
+// From<&str> for RGBAColor (colors.rs:230-262): "rrggbb" or "aarrggbb", optional '#', surrounding blanks trimmed; anything
+// else (wrong length, not hexadecimal) is the all-zero colour.  out = r, g, b, a.
+void rth_rgba8_from_html(const char *text, uint8_t out_rgba[4]) {
+    out_rgba[0] = out_rgba[1] = out_rgba[2] = out_rgba[3] = 0;
+    if (!text) return;
+    std::string s(text);
+    size_t b = 0, e = s.size();
+    while (b < e && isspace((unsigned char)s[b])) ++b;
+    while (e > b && isspace((unsigned char)s[e - 1])) --e;
+    s = s.substr(b, e - b);
+    if (s.empty()) return;
+    if (s[0] == '#') s = s.substr(1);
+    if (!(s.size() == 6 || s.size() == 8)) return;
+    uint32_t v = 0;
+    for (size_t i = 0; i < s.size(); ++i) {     // u32::from_str_radix(s, 16): digits only (a leading '+' is accepted by Rust: not here)
+        const char ch = s[i];
+        uint32_t d = ch >= '0' && ch <= '9' ? (uint32_t)(ch - '0') : ch >= 'a' && ch <= 'f' ? (uint32_t)(ch - 'a' + 10)
+                     : ch >= 'A' && ch <= 'F' ? (uint32_t)(ch - 'A' + 10) : 16u;
+        if (d > 15u) return;
+        v = (v << 4) | d;
+    }
+    if (s.size() == 6) v |= 0xFFu << 24;
+    out_rgba[0] = (uint8_t)((v >> 16) & 0xFFu);     // from_u32 for u8 (colors.rs:15-22)
+    out_rgba[1] = (uint8_t)((v >> 8) & 0xFFu);
+    out_rgba[2] = (uint8_t)(v & 0xFFu);
+    out_rgba[3] = (uint8_t)((v >> 24) & 0xFFu);
 }
 
 /* ------------------------------------------------------------------ work blocks */

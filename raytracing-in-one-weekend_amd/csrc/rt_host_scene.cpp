@@ -850,7 +850,9 @@ int build_blocks(Builder &b, const rth_scene_assets *assets) {
     floor_and_sky(b, image_tex(s, assets->uvgrid01), world);
     auto checkers = [&](uint32_t odd, uint32_t even) {
         auto tex = [&](uint32_t c) {
-            return rth_add_solid_texture(s, (float)((c >> 16) & 0xFF) / 255.0f, (float)((c >> 8) & 0xFF) / 255.0f, (float)(c & 0xFF) / 255.0f);
+            float rgba[4];
+            rth_color_from_u32(c, rgba);
+            return rth_add_solid_texture(s, rgba[0], rgba[1], rgba[2]);
         };
         int o = tex(odd), e = tex(even);
         return rth_add_lambertian(s, rth_add_checker_texture(s, o, e, 4.0f));

@@ -278,7 +278,9 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
     tv.inv = r.o; tv.oi = r.o;
     const float T_MIN = 0.001f;
     RG_BEGIN(RG_TRAV_ALL);
+    uint32_t dbg_turns = 0;
     for (;;) {
+        if (kTimers) ++dbg_turns;
         const unsigned long long m_idle = __ballot(idx < 0);
         const uint32_t n_idle = (uint32_t)__popcll(m_idle);
         if (n_idle == 64u && exhausted) break;
@@ -341,6 +343,7 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
         }
     }
     RG_END(RG_TRAV_ALL);
+    if (kTimers && !STATS && lane == 0) atomicMax(&stats[RT_STAT_WORDS], (unsigned long long)dbg_turns);   // development builds: longest wave, in loop turns
     if (STATS || kTimers) flush_counters<STATS>(cnt, 0u, stats);
 }
 

@@ -340,6 +340,329 @@ def quadric_hit(kind, prm, m, o, d, t_min, t_max):
     return {"t": bits(thit), "p": vbits(p), "normal": vbits(nn), "front_face": int(front), "v": bits(v)}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 2: the parts of the path that round 1 left resting on one reading of the Rust (VERDICT r1 "weak" 1): triangle test
+# and cull, MovingSphere, Translate / RotateY records, and one whole bounce of ray_color for metal, dielectric, Lambertian
+# (mixture pdf, its clamp, rectangle and sphere pdf_value) and ConstantMedium::hit with given random numbers.
+
+def scale(k, v):
+    return [k * x for x in v]
+
+
+def add(a, b):
+    return [a[0] + b[0], a[1] + b[1], a[2] + b[2]]
+
+
+def neg(v):
+    return [-x for x in v]
+
+
+def length(v):
+    return np.sqrt(dot(v, v))
+
+
+def hit_record_new(d, outward):
+    """hittable.rs:17-41: (normal, front_face)"""
+    front = bool(dot(d, outward) < 0)
+    return (outward if front else neg(outward)), front
+
+
+def tri_hit(verts, o, d, t_min, t_max):
+    """triangle_mesh.rs:185-243 (ray_triangle_intersect_test); verts = 3 x (pos, normal, uv)"""
+    (p1, n1, uv1), (p2, n2, uv2), (p3, n3, uv3) = [(vec(v[0:3]), vec(v[3:6]), vec(v[6:8])) for v in verts]
+    o, d, t_min, t_max = vec(o), vec(d), F(t_min), F(t_max)
+    e1, e2 = sub(p2, p1), sub(p3, p1)
+    s1 = cross(d, e2)
+    div = dot(s1, e1)
+    if div == 0:
+        return None
+    inv_div = F(1) / div
+    dd = sub(o, p1)
+    b1 = dot(dd, s1) * inv_div
+    if b1 < 0 or b1 > 1:
+        return None
+    s2 = cross(dd, e1)
+    b2 = dot(d, s2) * inv_div
+    if b2 < 0 or (b1 + b2) > 1:
+        return None
+    t = dot(e2, s2) * inv_div
+    if t < t_min or t > t_max:
+        return None
+    b0 = F(1) - b1 - b2
+    n = normalize(add(add(scale(b0, n1), scale(b1, n2)), scale(b2, n3)))
+    if dot(d, n) > 0:
+        return None
+    uv = [b0 * uv1[i] + b1 * uv2[i] + b2 * uv3[i] for i in range(2)]
+    nn, front = hit_record_new(d, n)
+    return {"t": bits(t), "normal": vbits(nn), "front_face": int(front), "uv": vbits(uv)}
+
+
+def mesh_hit(verts, o, d, t_min, t_max):
+    """TriangleMesh::hit (triangle_mesh.rs:245-268) for a one-triangle, one-node mesh: both boxes, then the triangle"""
+    pts = np.array([v[0:3] for v in verts], np.float32)
+    mn, mx = pts.min(axis=0), pts.max(axis=0)
+    if not aabb_hit(mn, mx, o, d, t_min, t_max):
+        return None
+    return tri_hit(verts, o, d, t_min, t_max)
+
+
+def moving_center(c0, c1, t0, t1, time):
+    """sphere.rs:144-147"""
+    k = (F(time) - F(t0)) / (F(t1) - F(t0))
+    return add(vec(c0), scale(k, sub(vec(c1), vec(c0))))
+
+
+def moving_sphere_hit(c0, c1, t0, t1, r, o, d, time, t_min, t_max):
+    """sphere.rs:151-201"""
+    return sphere_hit([float(x) for x in moving_center(c0, c1, t0, t1, time)], r, o, d, t_min, t_max)
+
+
+def wrapped_hit(inner, sin_t, cos_t, offset, o, d, t_min, t_max):
+    """Translate(RotateY(obj)) (transform.rs:28-45, 116-144).  inner(o, d, t_min, t_max) -> (t, p, outward_normal_as_returned,
+    front_face) of the wrapped object in ITS frame (its own HitRecord::new already applied), or None."""
+    o, d, off, s, c = vec(o), vec(d), vec(offset), F(sin_t), F(cos_t)
+    to = sub(o, off)                                                   # Translate: the ray moves back
+    ro = [c * to[0] - s * to[2], to[1], s * to[0] + c * to[2]]         # RotateY :117-124
+    rd = [c * d[0] - s * d[2], d[1], s * d[0] + c * d[2]]
+    h = inner(ro, rd, t_min, t_max)
+    if h is None:
+        return None
+    t, p, n, front = h
+    p = [c * p[0] + s * p[2], p[1], -s * p[0] + c * p[2]]              # :131-136 (front_face kept)
+    n = [c * n[0] + s * n[2], n[1], -s * n[0] + c * n[2]]
+    p = add(p, off)                                                    # Translate: HitRecord::new again with the moved ray
+    nn, front = hit_record_new(d, n)
+    return {"t": bits(t), "normal": vbits(nn), "front_face": int(front), "p": vbits(p)}
+
+
+def sphere_inner(center, radius):
+    def f(o, d, t_min, t_max):
+        c, r = vec(center), F(radius)
+        oc = sub(o, c)
+        a, half_b = dot(d, d), dot(oc, d)
+        cc = dot(oc, oc) - r * r
+        disc = half_b * half_b - a * cc
+        if disc < 0:
+            return None
+        sq = np.sqrt(disc)
+        root = (-half_b - sq) / a
+        if root < t_min or t_max < root:
+            root = (-half_b + sq) / a
+            if root < t_min or t_max < root:
+                return None
+        p = at(o, d, root)
+        n = [(p[i] - c[i]) / r for i in range(3)]
+        nn, front = hit_record_new(d, n)
+        return root, p, nn, front
+    return f
+
+
+def rect_inner(kind, a0, a1, b0, b1, k):
+    A, B, AX = {"xy": (0, 1, 2), "xz": (0, 2, 1), "yz": (1, 2, 0)}[kind]
+    def f(o, d, t_min, t_max):
+        a0_, a1_, b0_, b1_, k_ = F(a0), F(a1), F(b0), F(b1), F(k)
+        with np.errstate(all="ignore"):
+            t = (k_ - o[AX]) / d[AX]
+        if t < t_min or t > t_max:
+            return None
+        a, b = o[A] + t * d[A], o[B] + t * d[B]
+        if a < a0_ or a > a1_ or b < b0_ or b > b1_:
+            return None
+        n = [F(0)] * 3
+        n[AX] = F(1)
+        nn, front = hit_record_new(d, n)
+        return t, at(o, d, t), nn, front
+    return f
+
+
+def logf_(x):
+    """include/rt_portable_math.h logf_ (Cephes logf; this backend's ln, used by oracle and kernels instead of libm)"""
+    x = F(x)
+    b = int(np.array(x, np.float32).view(np.uint32))
+    e = (b >> 23) - 126
+    x = np.array((b & 0x007fffff) | 0x3f000000, np.uint32).view(np.float32)
+    if x < F(0.707106781186547524):
+        e -= 1
+        x = x + x - F(1)
+    else:
+        x = x - F(1)
+    z = x * x
+    y = F(7.0376836292E-2)
+    for cf in (-1.1514610310E-1, 1.1676998740E-1, -1.2420140846E-1, 1.4249322787E-1, -1.6668057665E-1, 2.0000714765E-1,
+               -2.4999993993E-1, 3.3333331174E-1):
+        y = y * x + F(cf)
+    y = y * x * z
+    fe = F(e)
+    y = y + (F(-2.12194440e-4) * fe)
+    y = y + (F(-0.5) * z)
+    z = x + y
+    return z + F(0.693359375) * fe
+
+
+def reflect(v, n):
+    """vec3.rs:740-753"""
+    k = F(2) * dot(v, n)
+    return sub(v, scale(k, n))
+
+
+def refract_v(uv, n, eta):
+    cos_theta = dot(neg(uv), n)
+    par = scale(eta, add(uv, scale(cos_theta, n)))
+    with np.errstate(all="ignore"):
+        k = -np.sqrt(F(1) - dot(par, par))
+    return add(par, scale(k, n))
+
+
+def schlick_f(cosine, ior):
+    r0 = (F(1) - ior) / (F(1) + ior)
+    r0 = r0 * r0
+    x = F(1) - cosine
+    x2 = x * x
+    return r0 + (F(1) - r0) * (x * (x2 * x2))
+
+
+def onb_axes(n):
+    w = normalize(n)
+    a = vec([0, 1, 0]) if abs(w[0]) > F(0.9) else vec([1, 0, 0])
+    v = normalize(cross(w, a))
+    return cross(w, v), v, w
+
+
+def metal_bounce(albedo, fuzz, d, normal, xi):
+    """metal.rs:20-37 + types.rs:87-104; xi = the uniform numbers drawn (three per try of random_in_unit_sphere)"""
+    d, n, fuzz = vec(d), vec(normal), F(fuzz)
+    reflected = reflect(d, normalize(n))
+    used = 0
+    while True:
+        p = [F(xi[used + i]) * (F(1) - F(-1)) + F(-1) for i in range(3)]     # random_real_range(-1, 1) = u * (hi - lo) + lo
+        used += 3
+        if dot(p, p) >= 1:
+            continue
+        break
+    scattered = add(reflected, scale(fuzz, p))
+    if not dot(scattered, n) > 0:
+        return {"kind": 1, "used": used}
+    return {"kind": 2, "dir": vbits(scattered), "attenuation": vbits(vec(albedo)), "used": used}
+
+
+def dielectric_bounce(ior, d, normal, front_face, xi):
+    """dielectric.rs:16-68"""
+    d, n, ior = vec(d), vec(normal), F(ior)
+    eta = F(1) / ior if front_face else ior
+    uv = normalize(d)
+    c = dot(neg(uv), n)
+    cos_theta = c if c < 1 else F(1)                                          # f32::min
+    sin_theta = np.sqrt(F(1) - cos_theta * cos_theta)
+    if eta * sin_theta > 1:
+        return {"kind": 2, "dir": vbits(reflect(uv, normalize(n))), "attenuation": vbits(vec([1, 1, 1])), "used": 0}
+    if F(xi[0]) < schlick_f(cos_theta, eta):
+        out = reflect(uv, n)
+    else:
+        out = refract_v(uv, n, eta)
+    return {"kind": 2, "dir": vbits(out), "attenuation": vbits(vec([1, 1, 1])), "used": 1}
+
+
+def rect_pdf_value(kind, a0, a1, b0, b1, k, origin, v):
+    """rectangles.rs:54-67 (and the XZ / YZ twins): hit with (0.001, f32::MAX), then distance^2 / (cosine * area)"""
+    h = rect_inner(kind, a0, a1, b0, b1, k)(vec(origin), vec(v), F(0.001), F(np.finfo(np.float32).max))
+    if h is None:
+        return F(0)
+    t, _, nn, _ = h
+    v = vec(v)
+    area = (F(a1) - F(a0)) * (F(b1) - F(b0))
+    distance_squared = t * t * dot(v, v)
+    cosine = abs(dot(v, nn) / length(v))
+    return distance_squared / (cosine * area)
+
+
+def sphere_pdf_value(center, radius, origin, v):
+    """sphere.rs:91-105"""
+    h = sphere_inner(center, radius)(vec(origin), vec(v), F(0.001), F(np.finfo(np.float32).max))
+    if h is None:
+        return F(0)
+    c, r, o = vec(center), F(radius), vec(origin)
+    co = sub(c, o)
+    cos_theta_max = np.sqrt(F(1) - r * r / dot(co, co))
+    solid_angle = F(2) * F(np.pi) * (F(1) - cos_theta_max)
+    return F(1) / solid_angle
+
+
+def cosine_pdf_value(normal, direction):
+    """pdf.rs:27-35"""
+    _, _, w = onb_axes(vec(normal))
+    cosine = dot(normalize(vec(direction)), w)
+    return F(0) if cosine <= 0 else cosine * F(0.318309886183790671537767526745028724)
+
+
+def lambertian_bounce(p, normal, lights, xi):
+    """camera.rs:268-300 with lambertian.rs:32-52, pdf.rs:57-79, hittable_list.rs:58-76: the scattered direction, the mixture
+    pdf value after the clamp and the scattering pdf.  lights = list of ("rect", kind, a0, a1, b0, b1, k) / ("sphere", c, r).
+    Cosine sampling is only used with r1 = 0 (phi = 0: cos = 1, sin = 0 exactly), the sphere light is never sampled."""
+    p, n = vec(p), vec(normal)
+    used = 1
+    if F(xi[0]) < F(0.5):                                                      # MixturePdf::generate: lights first
+        k = int(F(xi[1]) * F(len(lights)))                                     # (this backend's random_int for a given number)
+        k = min(k, len(lights) - 1)
+        used = 2
+        L = lights[k]
+        assert L[0] == "rect"
+        _, kind, a0, a1, b0, b1, kk = L
+        A, B, AX = {"xy": (0, 1, 2), "xz": (0, 2, 1), "yz": (1, 2, 0)}[kind]
+        pt = [F(0)] * 3
+        pt[A] = F(xi[2]) * (F(a1) - F(a0)) + F(a0)
+        pt[B] = F(xi[3]) * (F(b1) - F(b0)) + F(b0)
+        pt[AX] = F(kk)
+        used = 4
+        direction = sub(pt, p)                                                 # rectangles.rs:69-77
+    else:
+        r1, r2 = F(xi[1]), F(xi[2])
+        assert r1 == 0
+        used = 3
+        z = np.sqrt(F(1) - r2)
+        local = [F(1) * np.sqrt(r2), F(0) * np.sqrt(r2), z]                    # types.rs:141-151 at phi = 0
+        u, v, w = onb_axes(n)
+        direction = add(add(scale(local[0], u), scale(local[1], v)), scale(local[2], w))
+    weight = F(1) / F(len(lights))
+    lsum = F(0)
+    for L in lights:                                                           # hittable_list.rs:58-68
+        val = rect_pdf_value(*L[1:], p, direction) if L[0] == "rect" else sphere_pdf_value(L[1], L[2], p, direction)
+        lsum = lsum + weight * val
+    pdf_val = F(0.5) * lsum + F(0.5) * cosine_pdf_value(n, direction)
+    if abs(pdf_val) < F(1.0E-5):
+        pdf_val = F(1.0E-4) if not np.signbit(pdf_val) else F(-1.0E-4)
+    cosine = dot(n, normalize(direction))
+    spdf = F(0) if cosine < 0 else cosine / F(np.pi)
+    return {"kind": 3, "dir": vbits(direction), "pdf": bits(pdf_val), "scattering_pdf": bits(spdf), "used": used}
+
+
+def medium_hit(center, radius, density, o, d, t_min, t_max, xi):
+    """constant_medium.rs:46-94 over a sphere boundary; returns t or None"""
+    big = F(np.finfo(np.float32).max)
+    o, d = vec(o), vec(d)
+    h1 = sphere_inner(center, radius)(o, d, -big, big)
+    if h1 is None:
+        return None
+    h2 = sphere_inner(center, radius)(o, d, h1[0] + F(0.0001), big)
+    if h2 is None:
+        return None
+    t1, t2 = h1[0], h2[0]
+    if t1 < F(t_min):
+        t1 = F(t_min)
+    if t2 > F(t_max):
+        t2 = F(t_max)
+    if t1 >= t2:
+        return None
+    if t1 < 0:
+        t1 = F(0)
+    ray_length = length(d)
+    inside = (t2 - t1) * ray_length
+    neg_inv_density = F(-1) / F(density)
+    hit_distance = neg_inv_density * logf_(xi)
+    if hit_distance > inside:
+        return None
+    return t1 + hit_distance / ray_length
+
+
 def main():
     out = {}
     sph = []
@@ -440,6 +763,112 @@ def main():
                               "t_max": "inf" if t_max == float("inf") else t_max, "hit": h})
                 kept += 1
     out["quadric"] = quads
+
+    # ---- round 2 ----------------------------------------------------------------------------------------------------
+    tri_v = [[0.0, 0.0, 5.0, 0.0, 0.2, -1.0, 0.0, 0.0], [2.0, 0.25, 5.5, 0.1, 0.0, -1.0, 1.0, 0.0], [0.5, 2.0, 4.5, 0.0, -0.1, -1.0, 0.25, 1.0]]
+    tris = []
+    for o, d, t_min, t_max in [
+        ([0.7, 0.6, 0.0], [0.02, 0.01, 1.0], 0.001, np.inf),           # front side (normals point to -z): hit
+        ([0.7, 0.6, 10.0], [0.02, 0.01, -1.0], 0.001, np.inf),         # from behind: culled by dot(d, n) > 0
+        ([0.7, 0.6, 0.0], [0.02, 0.01, 1.0], 0.001, 4.0),              # beyond t_max
+        ([3.0, 3.0, 0.0], [0.0, 0.0, 1.0], 0.001, np.inf),             # outside the triangle (inside the mesh box)
+        ([0.0, 0.0, 0.0], [0.0, 0.0, 1.0], 0.001, np.inf),             # through vertex 1: b1 = b2 = 0 is inside
+        ([0.7, 0.6, 0.0], [1.0, 0.125, 0.25], 0.001, np.inf),          # in the triangle's plane: div == 0 exactly
+        ([1.1, 0.9, -3.0], [-0.05, 0.02, 1.0], 0.001, np.inf),
+    ]:
+        tris.append({"verts": tri_v, "o": o, "d": d, "t_min": t_min, "t_max": "inf" if t_max == np.inf else t_max,
+                     "hit": mesh_hit(tri_v, o, d, t_min, t_max), "triangle_alone": tri_hit(tri_v, o, d, t_min, t_max)})
+    flat = [[0.0, 0.0, 5.0, 0, 0, -1, 0, 0], [1.0, 0.0, 5.0, 0, 0, -1, 1, 0], [0.0, 1.0, 5.0, 0, 0, -1, 0, 1]]
+    out["triangle"] = tris
+    # a mesh that lies in an axis plane has a box of zero thickness, which Aabb::hit never reports (tmax <= tmin): never hit
+    out["triangle_flat_mesh"] = {"verts": flat, "o": [0.2, 0.2, 0.0], "d": [0.0, 0.0, 1.0], "t_min": 0.001, "t_max": "inf",
+                                 "hit": mesh_hit(flat, [0.2, 0.2, 0.0], [0.0, 0.0, 1.0], 0.001, np.inf),
+                                 "triangle_alone": tri_hit(flat, [0.2, 0.2, 0.0], [0.0, 0.0, 1.0], 0.001, np.inf)}
+    mov = []
+    for c0, c1, t0, t1, r, o, d, time in [
+        ([0, 0, 0], [0, 0.5, 0], 0.0, 1.0, 0.2, [0.05, 0.1, -3.0], [0.0, 0.02, 1.0], 0.0),
+        ([0, 0, 0], [0, 0.5, 0], 0.0, 1.0, 0.2, [0.05, 0.1, -3.0], [0.0, 0.02, 1.0], 0.37),
+        ([0, 0, 0], [0, 0.5, 0], 0.0, 1.0, 0.2, [0.05, 0.1, -3.0], [0.0, 0.02, 1.0], 1.0),      # centre has moved out of the ray
+        ([1, 0.2, -2], [1.3, 0.6, -2.2], 0.25, 0.75, 0.3, [0.0, 0.0, 3.0], [0.3, 0.12, -1.5], 0.6),
+        ([1, 0.2, -2], [1.3, 0.6, -2.2], 0.25, 0.75, 0.3, [0.0, 0.0, 3.0], [0.3, 0.12, -1.5], 2.5),   # a time outside the shutter (isotropic.rs:32)
+    ]:
+        mov.append({"c0": c0, "c1": c1, "time0": t0, "time1": t1, "radius": r, "o": o, "d": d, "time": time,
+                    "hit": moving_sphere_hit(c0, c1, t0, t1, r, o, d, time, 0.001, np.inf)})
+    out["moving_sphere"] = mov
+    sin15, cos15 = float(F(0.25881904)), float(F(0.9659258))                 # any pair works: the wrapper only multiplies by them
+    wraps = []
+    for inner_desc, sincos, off, o, d in [
+        (("sphere", [0, 0, 0], 1.0), (sin15, cos15), [2, 0.5, -1], [2.2, 0.4, -6.0], [0.01, 0.02, 1.0]),
+        (("sphere", [0.5, 0, 0.25], 0.75), (float(F(-0.30901699)), float(F(0.95105652))), [-1, 0, 3], [0.0, 0.3, -4.0], [-0.1, -0.03, 1.0]),
+        (("rect", "xy", 0, 165, 0, 330, 165), (sin15, cos15), [265, 0, 295], [278, 278, -800], [0.05, -0.2, 1.0]),   # Cornell's tall box, front side
+        (("rect", "yz", 0, 330, 0, 165, 0), (sin15, cos15), [265, 0, 295], [278, 278, -800], [0.02, -0.25, 1.0]),
+        (("rect", "xz", 0, 165, 0, 165, 330), (sin15, cos15), [265, 0, 295], [300, 540, 300], [0.1, -1.0, 0.2]),     # its top, from above
+        (("rect", "xy", 0, 165, 0, 330, 165), (sin15, cos15), [265, 0, 295], [278, 278, -800], [0.9, -0.2, 1.0]),    # miss
+    ]:
+        if inner_desc[0] == "sphere":
+            inner = sphere_inner(inner_desc[1], inner_desc[2])
+        else:
+            inner = rect_inner(*inner_desc[1:])
+        h = wrapped_hit(inner, sincos[0], sincos[1], off, o, d, F(0.001), F(np.inf))
+        wraps.append({"inner": list(inner_desc), "sin": sincos[0], "cos": sincos[1], "offset": off, "o": o, "d": d, "hit": h})
+    out["wrapped"] = wraps
+    # one bounce of ray_color with given random numbers
+    bounces = []
+    def sphere_rec(center, radius, o, d):
+        h = sphere_inner(center, radius)(vec(o), vec(d), F(0.001), F(np.inf))
+        return h                                                               # t, p, normal (face-forwarded), front
+    for albedo, fuzz, o, d, xi in [
+        ([0.8, 0.6, 0.2], 0.0, [0, 0, -3], [0.1, 0.2, 1.0], [0.5, 0.5, 0.5]),
+        ([0.8, 0.6, 0.2], 0.3, [0, 0, -3], [0.1, 0.2, 1.0], [0.99, 0.99, 0.99, 0.25, 0.75, 0.5]),          # first try rejected (|p|^2 >= 1)
+        ([0.7, 0.7, 0.7], 1.0, [0, 0.95, -3], [0.0, 0.0, 1.0], [0.5, 0.1, 0.5]),                            # grazing + fuzz pushes it below the surface: absorbed
+    ]:
+        t, p, n, front = sphere_rec([0, 0, 0], 1.0, o, d)
+        e = metal_bounce(albedo, fuzz, d, n, xi)
+        bounces.append({"material": "metal", "albedo": albedo, "fuzz": fuzz, "o": o, "d": d, "xi": xi, "t": bits(t), "expect": e})
+    for ior, o, d, xi in [
+        (1.5, [0, 0, -3], [0.1, 0.2, 1.0], [0.9]),            # front face, refracts
+        (1.5, [0, 0, -3], [0.1, 0.2, 1.0], [0.0]),            # front face, Schlick reflection
+        (1.5, [0, 0, 0.2], [0.3, 0.1, 1.0], [0.9]),           # from inside: back face, eta = 1.5, refracts out
+        (1.5, [0.0, 0.9, 0.0], [1.0, 0.05, 0.0], [0.9]),      # from inside at a grazing angle: total internal reflection, no number drawn
+    ]:
+        t, p, n, front = sphere_rec([0, 0, 0], 1.0, o, d)
+        e = dielectric_bounce(ior, d, n, front, xi)
+        bounces.append({"material": "dielectric", "ior": ior, "o": o, "d": d, "xi": xi, "t": bits(t), "expect": e})
+    lights = [("rect", "xz", 213, 343, 227, 332, 554), ("sphere", [190, 90, 190], 90.0)]                  # scene_cornell_box's `lights`
+    for o, d, xi in [
+        ([278, 278, -800], [0.0, -0.3, 1.0], [0.25, 0.1, 0.5, 0.5]),       # floor hit; light sampling, rectangle, its centre
+        ([278, 278, -800], [0.0, -0.3, 1.0], [0.25, 0.49, 0.0, 1.0 - 2 ** -24]),   # a corner of the light
+        ([278, 278, -800], [0.0, -0.3, 1.0], [0.75, 0.0, 0.5]),            # cosine sampling at phi = 0
+        ([278, 278, -800], [0.0, -0.3, 1.0], [0.75, 0.0, 1.0 - 2 ** -24]), # cosine sampling, grazing: z -> 2^-12
+        ([278, 278, -800], [0.0, -0.3, 1.0], [0.75, 0.0, 0.0]),            # straight up the normal: hits the light rectangle? (x, z decide)
+        ([278, 278, -800], [0.0, -0.3, 1.0], [0.75, 0.0, 1.0]),            # r2 = 1 (the reference's f64 -> f32 cast can give it): z = 0, in the
+                                                                           # surface, both pdfs 0 -> the clamp of camera.rs:279-288 makes it 1e-4
+    ]:
+        h = rect_inner("xz", 0, 555, 0, 555, 0)(vec(o), vec(d), F(0.001), F(np.inf))      # Cornell floor
+        t, p, n, front = h
+        e = lambertian_bounce(p, n, lights, xi)
+        bounces.append({"material": "lambertian", "o": o, "d": d, "xi": xi, "t": bits(t), "expect": e})
+    out["bounce"] = bounces
+    meds = []
+    for o, d, xi, t_max in [
+        ([0, 0, -5], [0, 0, 1.0], 0.5, np.inf), ([0, 0, -5], [0, 0, 1.0], 0.999, np.inf), ([0, 0, -5], [0, 0, 1.0], 1e-30, np.inf),
+        ([0, 0.5, 0], [0.3, 0.1, 1.0], 0.25, np.inf),       # origin inside the boundary: rec1.t < 0 is clamped to t_min
+        ([0, 0, -5], [0, 0.1, 2.0], 0.5, np.inf),           # direction not unit length
+        ([0, 3, -5], [0, 0, 1.0], 0.5, np.inf),             # misses the boundary
+    ]:
+        t = medium_hit([0, 0, 0], 2.0, 0.2, o, d, 0.001, t_max, xi)
+        meds.append({"center": [0, 0, 0], "radius": 2.0, "density": 0.2, "o": o, "d": d, "xi": xi, "t": None if t is None else bits(t)})
+    out["medium"] = meds
+    # the reference's own known answers next to the path: math/src/mat4.rs:657-667 and math/src/colors.rs:589-629
+    out["mat4_transpose"] = {"m": list(range(16)), "result": [0, 4, 8, 12, 1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15]}
+    out["colors"] = {"html": [["eb4034", [235, 64, 52, 255]], ["#eb4034", [235, 64, 52, 255]], ["#ffeb4034", [235, 64, 52, 255]],
+                              ["ff34eb9e", [52, 235, 158, 255]], ["#ff34eb9e", [52, 235, 158, 255]], ["jdk4fxuu", [0, 0, 0, 0]]],
+                     "to_u32": [[[52, 235, 158, 255], 0xff34eb9e]]}
+    inv_cases = []
+    for m in mats[1:]:
+        inv, _ = mat4_inverse_and_normal([[F(e) for e in row] for row in m])
+        inv_cases.append({"m": [x for row in m for x in row], "inverse": [bits(e) for row in inv for e in row]})
+    out["mat4_invert"] = inv_cases
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -53,6 +53,8 @@ def lib():
         L.orc_perlin.argtypes = [C.c_void_p, C.c_float * 3, C.c_int32]; L.orc_perlin.restype = C.c_float
         L.orc_resolve_rgb8.argtypes = [fp, C.c_int32, C.c_int32, u8p]; L.orc_resolve_rgb8.restype = None
         L.orc_set_trace.argtypes = [C.c_int32]; L.orc_set_trace.restype = None
+        L.orc_bounce.argtypes = [vp, C.c_float * 7, fp, C.c_int32, C.c_float * 22]
+        L.orc_mat4.argtypes = [C.c_int32, C.c_float * 16, C.c_float * 16]
         _lib = L
     return _lib
 
@@ -110,6 +112,17 @@ class OracleScene:
         assert st == 0
         return np.array(list(out), np.float32)
 
+    def bounce(self, o, d, xi, time=0.0):
+        """One bounce of ray_color with the given random numbers (orc_bounce): dict of kind, prim, t, p, normal, front_face,
+        dir, attenuation, pdf, scattering_pdf, emitted, used — floats as numpy float32."""
+        xs = np.ascontiguousarray(xi, np.float32)
+        out = (C.c_float * 22)()
+        st = lib().orc_bounce(self._h, (C.c_float * 7)(*o, *d, time), xs.ctypes.data_as(ffi.c_float_p), len(xs), out)
+        assert st == 0
+        v = np.array(list(out), np.float32)
+        return {"kind": int(v[0]), "prim": int(v[1]), "t": v[2], "p": v[3:6], "normal": v[6:9], "front_face": int(v[9]), "dir": v[10:13],
+                "attenuation": v[13:16], "pdf": v[16], "scattering_pdf": v[17], "emitted": v[18:21], "used": int(v[21])}
+
     def lights_pdf_value(self, o, v):
         return lib().orc_lights_pdf_value(self._h, (C.c_float * 3)(*o), (C.c_float * 3)(*v))
 
@@ -117,6 +130,14 @@ class OracleScene:
         if getattr(self, "_h", None):
             lib().orc_scene_destroy(self._h)
             self._h = None
+
+
+def mat4(op, m):
+    """The oracle's own matrix code: op 0 transpose, 1 invert, 2 adjoint (orc_mat4)."""
+    out = (C.c_float * 16)()
+    st = lib().orc_mat4(op, (C.c_float * 16)(*[float(x) for x in m]), out)
+    assert st == 0
+    return np.array(list(out), np.float32)
 
 
 def resolve_rgb8(sum_rgba, spp):

@@ -62,6 +62,26 @@ def test_golden_vectors_through_the_c_abi(rt, gpu):
         run(lambda s, m: [getattr(s, mk)(c["a0"], c["a1"], c["b0"], c["b1"], c["k"], m)], c)
 
 
+def test_round2_golden_vectors_through_the_c_abi(rt, gpu):
+    """The first-hit families of the widened numpy restatement (tests/golden/make_golden.py "round 2") via rt_trace_first_hit,
+    bit-exact: triangle test + cull + uv, MovingSphere at given times, Translate(RotateY(..)) records.  A mesh is compared with
+    the triangle test alone: the kernels' own padded boxes stand in for the mesh's Aabb::hit, which rejects rays whose box test
+    runs into 0 * inf ("BVH conservativeness") — one vector here (the ray through a vertex with d.x = d.y = 0)."""
+    from test_oracle_kat import check_first_hit, tri_scene, moving_scene, wrapped_scene
+    differ = 0
+    for c in KAT["triangle"]:
+        gpu.upload_scene(tri_scene(c["verts"]).flatten())
+        check_first_hit(gpu.trace_first_hit, dict(c, hit=c["triangle_alone"]), uv=True)
+        differ += c["hit"] != c["triangle_alone"]
+    assert differ == 1
+    for c in KAT["moving_sphere"]:
+        gpu.upload_scene(moving_scene(c).flatten())
+        check_first_hit(gpu.trace_first_hit, c, time=c["time"])
+    for c in KAT["wrapped"]:
+        gpu.upload_scene(wrapped_scene(c).flatten())
+        check_first_hit(gpu.trace_first_hit, c)
+
+
 def test_quadric_golden_vectors_through_the_c_abi(rt, gpu):
     """tests/golden/kat.json quadric + Transform vectors via rt_trace_first_hit: bit-exact."""
     from test_oracle_kat import check_quadric, quadric_scene

@@ -106,6 +106,31 @@ def graph_counts(scene):
     return g, types
 
 
+def test_reference_known_answers_for_transpose_and_colours(rt):
+    """The reference's own tests next to the path: math/src/mat4.rs:657-667 and math/src/colors.rs:589-629."""
+    L = rt._ffi.host_lib()
+    k = KAT["mat4_transpose"]
+    out = (C.c_float * 16)()
+    L.rth_mat4_transpose((C.c_float * 16)(*k["m"]), out)
+    assert list(out) == k["result"]
+    L.rth_rgba8_from_html.argtypes = [C.c_char_p, C.c_uint8 * 4]
+    L.rth_rgba8_to_u32.argtypes = [C.c_uint8] * 4; L.rth_rgba8_to_u32.restype = C.c_uint32
+    L.rth_color_from_u32.argtypes = [C.c_uint32, C.c_float * 4]
+    for text, want in KAT["colors"]["html"]:
+        got = (C.c_uint8 * 4)()
+        L.rth_rgba8_from_html(text.encode(), got)
+        assert list(got) == want, text
+    for rgba, want in KAT["colors"]["to_u32"]:
+        assert L.rth_rgba8_to_u32(*rgba) == want
+    f = (C.c_float * 4)()
+    L.rth_color_from_u32(0xff34eb9e, f)                             # colors.rs:34-41
+    assert list(f) == [np.float32(52) / np.float32(255), np.float32(235) / np.float32(255), np.float32(158) / np.float32(255), 1.0]
+    for bad in (b"", b"   ", b"12345", b"#1234567", b"+12345"):
+        got = (C.c_uint8 * 4)(9, 9, 9, 9)
+        L.rth_rgba8_from_html(bad, got)
+        assert list(got) == [0, 0, 0, 0]
+
+
 def test_scene_builders_object_counts(rt):
     s = rt.host.Scene.build("CornellBox")
     g, types = graph_counts(s)

@@ -373,3 +373,126 @@ def test_quadrics_and_transform_against_the_numpy_restatement(case):
     """tests/golden/make_golden.py restates cylinder.rs / cone.rs / paraboloid.rs / polynomial.rs / transform.rs / mat4.rs
     independently (numpy f32, one operation at a time): t, normal, front_face and v must agree bit for bit."""
     check_quadric(O.OracleScene(quadric_scene(case)).first_hit, case)
+
+
+# ---- round 2: the independent numpy restatement widened (tests/golden/make_golden.py "round 2") --------------------------
+# Triangle test and cull, MovingSphere, Translate(RotateY(..)) records: through first_hit, here for the oracle and in
+# tests/test_gpu_fullsize.py for the kernels.  One bounce of ray_color (metal, dielectric, Lambertian + mixture pdf + clamp +
+# rectangle / sphere pdf_value, ConstantMedium::hit) with GIVEN random numbers: through orc_bounce, oracle only — the kernels are
+# tied to the oracle by the bit-identical paths of the image tests (equal per-pixel ray counts, tests/test_gpu_parity.py).
+
+def tri_scene(verts):
+    v = np.array(verts, np.float32)
+    return scene_with(lambda s, m: [s.triangle_mesh(v, np.arange(3, dtype=np.uint32), np.array([[0, 3]], np.uint32), None, m)])
+
+
+def check_first_hit(first_hit, case, time=0.0, uv=False):
+    pid, t, n, ff, tuv = first_hit(ray(case["o"], case["d"], time), case.get("t_min", 0.001), tmax(case) if "t_max" in case else INF)
+    want = case["hit"]
+    if want is None:
+        assert pid[0] == 0xFFFFFFFF
+        return
+    assert pid[0] != 0xFFFFFFFF
+    assert t.view(np.uint32)[0] == want["t"]
+    assert list(n.view(np.uint32)[0]) == want["normal"]
+    assert ff[0] == want["front_face"]
+    if uv:
+        assert list(tuv.view(np.uint32)[0]) == want["uv"]
+
+
+@pytest.mark.parametrize("case", KAT["triangle"], ids=lambda c: "hit" if c["hit"] else "none")
+def test_triangle_and_cull(case):
+    """triangle_mesh.rs:185-268: barycentrics, interpolated normal, back-face cull, uv; the mesh and node boxes in front."""
+    check_first_hit(O.OracleScene(tri_scene(case["verts"]), mesh_nearest=False).first_hit, case, uv=True)
+
+
+def test_a_mesh_in_an_axis_plane_is_never_hit():
+    """Its Aabb has zero thickness and Aabb::hit (aabb3.rs:19-45) needs tmax > tmin: the triangle alone would be hit."""
+    c = KAT["triangle_flat_mesh"]
+    assert c["hit"] is None and c["triangle_alone"] is not None
+    check_first_hit(O.OracleScene(tri_scene(c["verts"]), mesh_nearest=False).first_hit, c)
+
+
+def moving_scene(c):
+    return scene_with(lambda s, m: [s.moving_sphere(c["c0"], c["c1"], c["time0"], c["time1"], c["radius"], m)])
+
+
+@pytest.mark.parametrize("case", KAT["moving_sphere"], ids=lambda c: "t%g" % c["time"])
+def test_moving_sphere(case):
+    check_first_hit(O.OracleScene(moving_scene(case)).first_hit, case, time=case["time"])
+
+
+def wrapped_scene(c):
+    def build(s, m):
+        i = c["inner"]
+        if i[0] == "sphere":
+            obj = s.sphere(i[1], i[2], m)
+        else:
+            obj = getattr(s, i[1] + "_rect")(i[2], i[3], i[4], i[5], i[6], m)
+        return [s.translate(s.rotate_y_sincos(obj, c["sin"], c["cos"]), c["offset"])]
+    return scene_with(build)
+
+
+@pytest.mark.parametrize("case", KAT["wrapped"], ids=lambda c: c["inner"][0] + ("" if c["hit"] else "-miss"))
+def test_translate_rotate_y_records(case):
+    """transform.rs:28-45, 116-144: the ray goes in through Translate then RotateY, the record comes back through both."""
+    check_first_hit(O.OracleScene(wrapped_scene(case)).first_hit, case)
+
+
+def bounce_scene(c):
+    s = rt.host.Scene()
+    if c["material"] == "lambertian":          # the Cornell floor with the scene's two lights
+        white = s.lambertian(s.solid(0.73, 0.73, 0.73))
+        objs = [s.xz_rect(0, 555, 0, 555, 0, white)]
+        lm = s.diffuse_light(s.solid(0, 0, 0))
+        lights = [s.xz_rect(213, 343, 227, 332, 554, lm), s.sphere((190, 90, 190), 90, lm)]
+    else:
+        m = s.metal(*c["albedo"], c["fuzz"]) if c["material"] == "metal" else s.dielectric(c["ior"])
+        objs = [s.sphere((0, 0, 0), 1.0, m)]
+        lights = [s.xz_rect(0, 1, 0, 1, 100, s.diffuse_light(s.solid(0, 0, 0)))]
+    s.set_roots(s.hittable_list(objs), s.hittable_list(lights))
+    return s
+
+
+@pytest.mark.parametrize("case", KAT["bounce"], ids=lambda c: c["material"])
+def test_one_bounce_with_given_random_numbers(case):
+    """metal.rs:20-37, dielectric.rs:16-68, lambertian.rs:32-52 + camera.rs:268-300 + pdf.rs + rectangles.rs:54-77 + sphere.rs:91-105."""
+    b = O.OracleScene(bounce_scene(case)).bounce(case["o"], case["d"], case["xi"])
+    e = case["expect"]
+    assert b["t"].view(np.uint32) == case["t"]
+    assert b["kind"] == e["kind"] and b["used"] == e["used"]
+    if e["kind"] >= 2:
+        assert list(b["dir"].view(np.uint32)) == e["dir"]
+    if e["kind"] == 2:
+        assert list(b["attenuation"].view(np.uint32)) == e["attenuation"]
+    if e["kind"] == 3:
+        assert b["pdf"].view(np.uint32) == e["pdf"] and b["scattering_pdf"].view(np.uint32) == e["scattering_pdf"]
+
+
+def test_mixture_pdf_clamp_is_reached():
+    """camera.rs:279-288: a grazing cosine sample away from both lights has a pdf below 1e-5 and gets +1e-4."""
+    vals = [f32(c["expect"]["pdf"]) for c in KAT["bounce"] if c["material"] == "lambertian"]
+    assert any(v == np.float32(1.0e-4) for v in vals) and any(v > np.float32(1.0e-3) for v in vals)
+
+
+@pytest.mark.parametrize("case", KAT["medium"], ids=lambda c: "xi%g" % c["xi"])
+def test_constant_medium_hit_with_a_given_number(case):
+    """constant_medium.rs:46-94 over a sphere boundary; ln is this backend's (rt_portable_math.h), restated in numpy too."""
+    s = rt.host.Scene()
+    fog = s.constant_medium(s.sphere(case["center"], case["radius"], s.lambertian(s.solid(1, 1, 1))), s.solid(1, 1, 1), case["density"])
+    s.set_roots(s.hittable_list([fog]), s.hittable_list([s.xz_rect(0, 1, 0, 1, 100, s.diffuse_light(s.solid(0, 0, 0)))]))
+    b = O.OracleScene(s).bounce(case["o"], case["d"], [case["xi"], 0.5, 0.5, 0.5, 0.5, 0.5, 0.5])
+    if case["t"] is None:
+        assert b["kind"] == 0
+    else:
+        assert b["kind"] != 0 and b["t"].view(np.uint32) == case["t"]
+        assert list(b["normal"]) == [1.0, 0.0, 0.0] and b["front_face"] == 1        # constant_medium.rs:86-88
+
+
+def test_reference_known_answers_for_mat4_and_the_oracles_matrix_code():
+    """math/src/mat4.rs:657-667 (transpose) against the oracle's own mat4_transpose, and its det / adjoint / invert
+    (mat4.rs:536-617, index typos included) against the numpy restatement, bit for bit."""
+    k = KAT["mat4_transpose"]
+    assert list(O.mat4(0, k["m"])) == k["result"]
+    for c in KAT["mat4_invert"]:
+        assert list(O.mat4(1, c["m"]).view(np.uint32)) == c["inverse"]

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, rtiow_loader
 rt = rtiow_loader.load()
 wl, spp = sys.argv[1], int(sys.argv[2])
-scene, params, camera, sampler = rt.configs.build(wl, samples_per_pixel=spp)
+over = {"image_width": int(sys.argv[3])} if len(sys.argv) > 3 else {}
+scene, params, camera, sampler = rt.configs.build(wl, samples_per_pixel=spp, **over)
 gpu = rt.backend.HipBackend(0); gpu.upload_scene(scene.flatten()); gpu.upload_sampler(sampler)
 _, st = gpu.render(params, camera, stats=True)
 # the timers come from the product kernels of a -DRT_REGION_TIMERS=1 build, printed on stderr by the library:
@@ -21,6 +22,7 @@ with tempfile.TemporaryFile() as f:
         os.close(saved)
     f.seek(0)
     err = f.read().decode()
+print("".join(l + "\n" for l in err.splitlines() if l.startswith("[rt-turns]")), end="")
 line_ = [l for l in err.splitlines() if l.startswith("[rt-regions]")]
 if not line_: sys.exit("library was not built with -DRT_REGION_TIMERS=1:\n" + err[-2000:])
 st["region_cycles"] = [int(x) for x in line_[-1].split()[1:]]
