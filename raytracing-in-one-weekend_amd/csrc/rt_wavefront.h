@@ -524,22 +524,29 @@ __global__ void __launch_bounds__(64) wf_tail_kernel(DScene sc, WfArgs w, PathQ 
             }
         }
         while (__ballot(alive) != 0ull) {
+            RG_BEGIN(RG_TRAV_ALL);
             for (;;) {      // the walk, "while-while" as in the traverse kernel
                 const bool on_node = alive && walk && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY;
                 phase_count<STATS>(cnt, PH_NODE, on_node);
+                RG_BEGIN(RG_NODE);
                 if (on_node) trav_node_step<STATS>(sc, T_MIN, tv, stack, cnt);
+                RG_END(RG_NODE);
                 const bool at_leaf = alive && walk && tv.ref < 0;
                 const unsigned long long m_leaf = __ballot(at_leaf);
                 const unsigned long long m_node = __ballot(alive && walk && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
                 if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
                     phase_count<STATS>(cnt, PH_LEAF, at_leaf);
+                    RG_BEGIN(RG_LEAF);
                     if (at_leaf) trav_leaf_step<STATS, EXT & (EXT_XFORM | EXT_TRI)>(sc, p.ps.ray, T_MIN, tv, stack, cnt);
+                    RG_END(RG_LEAF);
                 } else if (m_node == 0ull) {
                     break;
                 }
             }
+            RG_END(RG_TRAV_ALL);
             phase_count<STATS>(cnt, PH_SHADE, alive);
             bool survive = false;
+            RG_BEGIN(RG_SHADE_ALL);
             if (alive) {
                 finish_trace<STATS, EXT>(sc, p.ps.ray, T_MIN, INFINITY, tv, cnt);
                 survive = shade_hit<STATS, EXT>(sc, p.ps, tv.best, background, p.rng, cnt) && p.ps.depth > 0;
@@ -548,11 +555,14 @@ __global__ void __launch_bounds__(64) wf_tail_kernel(DScene sc, WfArgs w, PathQ 
                     alive = false;
                 }
             }
+            RG_END(RG_SHADE_ALL);
             phase_count<STATS>(cnt, PH_BEGIN, survive);
+            RG_BEGIN(RG_BEGIN_ALL);
             if (survive) {
                 if (STATS) { cnt.rays += 1; if (pixel_rays) atomicAdd(&pixel_rays[p.pixel], 1u); }
                 walk = begin_trace<STATS, EXT>(sc, p.ps.ray, T_MIN, INFINITY, p.rng, tv, cnt);
             }
+            RG_END(RG_BEGIN_ALL);
         }
     }
     if (STATS || kTimers) flush_counters<STATS>(cnt, 0u, stats);
