@@ -35,7 +35,7 @@ namespace rtk {
 #define RT_F32_MAX 3.40282347e+38f
 // traversal: run a leaf step once RT_LEAF_MIN lanes stand on a leaf (or nobody is on an inner node)
 #ifndef RT_LEAF_MIN
-#define RT_LEAF_MIN 20
+#define RT_LEAF_MIN 12
 #endif
 
 struct V3 {

@@ -240,6 +240,9 @@ __global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScen
 #ifndef RT_WF_FETCH_MIN
 #define RT_WF_FETCH_MIN 12     // refill when at least this many lanes of the wave are idle
 #endif
+#ifndef RT_LEAF_FRAC
+#define RT_LEAF_FRAC 4u        // traverse: a leaf step also runs once a quarter of the wave's live lanes hold a leaf
+#endif
 #ifndef RT_WF_NODE_STEPS
 #define RT_WF_NODE_STEPS 3     // node steps per turn of the traverse loop
 #endif
@@ -331,7 +334,10 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
         const bool has_leaf = idx >= 0 && pend != RT_BVH_EMPTY;
         const unsigned long long m_leaf = __ballot(has_leaf);
         const unsigned long long m_node = __ballot(idx >= 0 && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
-        if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
+        // ... or a RT_LEAF_FRAC-th of the lanes that still hold a ray: a wave that is draining (or thin from the start) would
+        // otherwise test a leaf only when every lane is stuck on its second one, i.e. walk on with a best.t that could be shorter
+        const uint32_t n_leaf = (uint32_t)__popcll(m_leaf), n_live = (uint32_t)__popcll(__ballot(idx >= 0));
+        if (m_leaf != 0ull && (n_leaf >= RT_LEAF_MIN || n_leaf * RT_LEAF_FRAC >= n_live || m_node == 0ull)) {
             phase_count<STATS>(cnt, PH_LEAF, has_leaf);
             RG_BEGIN(RG_LEAF);
             if (has_leaf) { trav_leaf_test<STATS, EXT>(sc, r, T_MIN, tv, pend, cnt); pend = RT_BVH_EMPTY; }
