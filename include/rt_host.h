@@ -105,7 +105,9 @@ typedef struct rth_scene_assets {
 } rth_scene_assets;
 
 /* name = a `Scene` variant of main.rs:93-104: "RandomWorld", "CornellBox", "Chapter2Final",
- * "MeshTest", "GeometricPrimitives", "Blocks", "TwoSpheres", "PerlinSpheres", "TexturedSpheres", "SimpleLight" — all ten.  seed feeds every random_* call of the builder (the reference is unseeded). */
+ * "MeshTest", "GeometricPrimitives", "Blocks", "TwoSpheres", "PerlinSpheres", "TexturedSpheres", "SimpleLight" — all ten — and
+ * "CornellBoxSmoke": scene_cornell_box_smoke (main.rs:524-683), which no `Scene` variant reaches; it is the reference's one use of a
+ * ConstantMedium over a boundary that is not a sphere.  seed feeds every random_* call of the builder (the reference is unseeded). */
 int rth_build_scene(rth_scene *s, const char *name, uint32_t seed, const rth_scene_assets *assets);
 
 /* ------------------------------------------------------------------ config (RON) */

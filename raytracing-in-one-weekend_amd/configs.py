@@ -29,6 +29,8 @@ WORKLOADS = {
     "PERLIN": dict(scene="PerlinSpheres"),
     "LIGHT": dict(scene="SimpleLight"),
     # not in the reference's defined_scenes (and not reachable from its scene switch): default_params, camera pulled back
+    # scene_cornell_box_smoke (main.rs:524-683): defined in the reference, reached by no `Scene` variant; Cornell's camera
+    "SMOKE": dict(scene="CornellBoxSmoke", config_scene="CornellBox", image_width=600, aspect_ratio=1.0),
     "EARTH": dict(scene="TexturedSpheres", config_scene="CornellBox", look_from=(13.0, 2.0, 3.0), look_at=(0.0, 0.0, 0.0),
                   vertical_fov=20.0, background=(0.7, 0.8, 1.0)),
 }
@@ -49,7 +51,7 @@ def workload(name, config=None, **overrides):
 def build(name, config=None, seed=SEED, **overrides):
     """Build everything a render needs: (Scene, RaytracerParams, rt_camera, MultiJitteredSampler)."""
     scene_name, params, mesh_grid = workload(name, config, **overrides)
-    need = {"RandomWorld": (), "CornellBox": (), "Chapter2Final": ("earthmap",),
+    need = {"RandomWorld": (), "CornellBox": (), "CornellBoxSmoke": (), "Chapter2Final": ("earthmap",),
             "MeshTest": ("uvgrid01", "uvgrid09", "teapot"), "Blocks": ("uvgrid01",),
             "GeometricPrimitives": ("uvgrid01", "uvgrid03", "uvgrid08", "uvgrid10"), "TwoSpheres": (), "SimpleLight": (),
             "PerlinSpheres": ("uvgrid01", "uvgrid03"), "TexturedSpheres": ("earthmap",)}[scene_name]

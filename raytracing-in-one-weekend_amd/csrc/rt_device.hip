@@ -588,6 +588,28 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         int32_t mat;
         memcpy(&mat, &s->media[i * RT_REC_FLOATS + 5], 4);
         if (mat < 0 || (uint32_t)mat >= s->n_materials) return fail(ctx, RT_E_INVALID, "medium %u: material out of range", i);
+        int32_t kind, first, count;
+        memcpy(&kind, &s->media[i * RT_REC_FLOATS + 7], 4);
+        if (kind == 0) continue;
+        if (kind != 1) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "medium %u: boundary kind %d", i, kind);
+        memcpy(&first, &s->media[i * RT_REC_FLOATS], 4);
+        memcpy(&count, &s->media[i * RT_REC_FLOATS + 1], 4);
+        // boundary slots: behind the always-list, plain spheres / rectangles (Translate / RotateY allowed), solid phase function
+        if (first < 0 || count < 1 || count > 64 || (uint64_t)first < (uint64_t)s->always_begin + s->always_count || (uint64_t)first + (uint64_t)count > s->n_slots)
+            return fail(ctx, RT_E_INVALID, "medium %u: boundary slots [%d, %d) outside the slot array's tail", i, first, first + count);
+        for (int32_t k = first; k < first + count; ++k) {
+            int32_t w4;
+            memcpy(&w4, &s->slots[(size_t)k * RT_SLOT_FLOATS + 4], 4);
+            const int type = w4 & 15, xf = (w4 >> 8) - 1;
+            int32_t flags = 0;
+            if (xf >= 0) memcpy(&flags, &s->xforms[(size_t)xf * RT_REC_FLOATS], 4);
+            if (!(type == RT_PRIM_SPHERE || (type >= RT_PRIM_XY_RECT && type <= RT_PRIM_YZ_RECT)) || (flags & 4))
+                return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "medium %u: boundary slot %d is not a sphere or rectangle under Translate / RotateY", i, k);
+        }
+        int32_t tex, tkind;
+        memcpy(&tex, &s->materials[(size_t)mat * RT_REC_FLOATS + 1], 4);
+        memcpy(&tkind, &s->textures[(size_t)tex * RT_REC_FLOATS], 4);
+        if (tkind == RTG_TEX_IMAGE) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "medium %u: an image texture on a non-sphere boundary is not supported (u, v of the boundary hit)", i);
     }
 
     int st = set_device(ctx);

@@ -80,6 +80,10 @@ struct Flattener {
     std::vector<uint8_t> always;   // per primitive: tested for every ray, never through the BVH (rt_api.h rt_prim_type)
     uint32_t next_id = 0;
     std::string err;
+    // the leaves of a ConstantMedium boundary that is not a plain sphere: slots behind the always-list, reached only through
+    // their medium's record; they take no primitive id (rt_scene_graph.h) and appear in no tree or list
+    std::vector<Slot> boundary;
+    bool boundary_mode = false;
 
     bool fail(const std::string &m) {
         if (err.empty()) err = m;
@@ -132,8 +136,9 @@ struct Flattener {
         int xf = xform_index(w);
         s.w[4] = i2f(type | (w.flip ? 16 : 0) | ((xf + 1) << 8));
         s.w[5] = i2f(material);
-        s.w[6] = i2f((int32_t)next_id++);
+        s.w[6] = i2f(boundary_mode ? -1 : (int32_t)next_id++);
         s.w[7] = scalar;
+        if (boundary_mode) { boundary.push_back(s); return; }
         Box wb = to_world(obj_box, w);
         // Conservative padding: the slab test must never cull a primitive whose own hit test
         // accepts the ray (DESIGN.md "BVH conservativeness").
@@ -158,7 +163,7 @@ struct Flattener {
         if (gtype == RTG_XY_RECT) { type = RT_PRIM_XY_RECT; b = Box{{f[0], f[2], k}, {f[1], f[3], k}}; }
         else if (gtype == RTG_XZ_RECT) { type = RT_PRIM_XZ_RECT; b = Box{{f[0], k, f[2]}, {f[1], k, f[3]}}; }
         else { type = RT_PRIM_YZ_RECT; b = Box{{k, f[0], f[2]}, {k, f[1], f[3]}}; }
-        out->rects.push_back((uint32_t)prims.size());
+        if (!boundary_mode) out->rects.push_back((uint32_t)prims.size());
         emit(type, w, material, q0, k, nullptr, b, nullptr);
     }
 
@@ -269,9 +274,34 @@ struct Flattener {
             if (n.child_count != 1) return fail("ConstantMedium needs one boundary");
             if (w.has_rot || w.has_trans || w.flip || w.matrix >= 0) return fail("ConstantMedium under a wrapper is not supported");
             const rtg_node &b = g->nodes[ch[0]];
-            if (b.type != RTG_SPHERE) return fail("ConstantMedium boundary must be a Sphere");
-            float rec[RT_REC_FLOATS] = {b.f[0], b.f[1], b.f[2], b.f[3], -1.0f / n.f[0] /* constant_medium.rs:24 */,
-                                        i2f(n.material), i2f((int32_t)next_id++), 0.0f};
+            if (b.type == RTG_SPHERE) {
+                float rec[RT_REC_FLOATS] = {b.f[0], b.f[1], b.f[2], b.f[3], -1.0f / n.f[0] /* constant_medium.rs:24 */,
+                                            i2f(n.material), i2f((int32_t)next_id++), 0.0f};
+                out->media.insert(out->media.end(), rec, rec + RT_REC_FLOATS);
+                return true;
+            }
+            // any other boundary (constant_medium.rs:52-58 takes a Hittable; scene_cornell_box_smoke, main.rs:642-680, uses
+            // Translate(RotateY(Block))): wrappers over ONE Block / rectangle / sphere.  Its leaves become boundary slots that the
+            // medium's record points at; boundary.hit() is then the list fold over them (block.rs:111-113, hittable_list.rs:39-50).
+            {
+                int32_t leaf = ch[0];
+                for (int d = 0; d < 8; ++d) {
+                    const rtg_node &k = g->nodes[leaf];
+                    if (k.type == RTG_TRANSLATE || k.type == RTG_ROTATE_Y || k.type == RTG_FLIP_FACE) { if (k.child_count != 1) return fail("wrapper needs one child"); leaf = g->children[k.child_begin]; }
+                    else break;
+                }
+                const int lt = g->nodes[leaf].type;
+                if (!(lt == RTG_BLOCK || lt == RTG_SPHERE || lt == RTG_XY_RECT || lt == RTG_XZ_RECT || lt == RTG_YZ_RECT))
+                    return fail("ConstantMedium boundary must be a Sphere, or a Block / rectangle / Sphere under Translate / RotateY");
+            }
+            const uint32_t id = next_id++;
+            const size_t first = boundary.size();
+            boundary_mode = true;
+            const bool ok = walk(ch[0], Wrap{}, depth + 1);
+            boundary_mode = false;
+            if (!ok) return false;
+            float rec[RT_REC_FLOATS] = {i2f((int32_t)first) /* + the number of other slots, added when the slot array is laid out */,
+                                        i2f((int32_t)(boundary.size() - first)), 0.0f, 0.0f, -1.0f / n.f[0], i2f(n.material), i2f((int32_t)id), i2f(1)};
             out->media.insert(out->media.end(), rec, rec + RT_REC_FLOATS);
             return true;
         }
@@ -458,7 +488,7 @@ int rth_flatten_opts(const rtg_graph *g, uint32_t flags, rth_flat **out_flat) {
     if (!g || !out_flat) { set_error("null argument"); return RT_E_INVALID; }
     if (g->world_root < 0 || g->lights_root < 0) { set_error("scene roots are not set"); return RT_E_INVALID; }
     auto flat = std::make_unique<rth_flat>();
-    Flattener fl{g, flat.get(), {}, {}, {}, {}, 0, {}};
+    Flattener fl{g, flat.get(), {}, {}, {}, {}, 0, {}, {}, false};
     if (!fl.walk(g->world_root, Wrap{}, 0)) {
         set_error("flatten: %s", fl.err.c_str());
         return RT_E_UNSUPPORTED_PRIMITIVE;
@@ -640,6 +670,21 @@ int rth_flatten_opts(const rtg_graph *g, uint32_t flags, rth_flat **out_flat) {
     }
     for (auto &m : flat->moving) m = new_index[m];
     for (auto &m : flat->rects) m = new_index[m];
+    if (!fl.boundary.empty()) {     // boundary slots of media go behind everything else; their records learn where
+        if (flags & RTH_FLATTEN_DEVICE_BVH) { set_error("flatten: a device-built BVH and a ConstantMedium over a non-sphere boundary are not supported together"); return RT_E_UNSUPPORTED_PRIMITIVE; }
+        const size_t base = flat->slots.size();
+        flat->slots.insert(flat->slots.end(), fl.boundary.begin(), fl.boundary.end());
+        flat->attrs.resize(flat->slots.size());
+        for (size_t m = 0; m * RT_REC_FLOATS < flat->media.size(); ++m) {
+            float *rec = &flat->media[m * RT_REC_FLOATS];
+            int32_t kind, first;
+            memcpy(&kind, rec + 7, 4);
+            if (kind != 1) continue;
+            memcpy(&first, rec, 4);
+            first += (int32_t)base;
+            memcpy(rec, &first, 4);
+        }
+    }
     if (!flat->has_tris) flat->attrs.clear();
     *out_flat = flat.release();
     return RT_OK;

@@ -660,6 +660,33 @@ int build_cornell_box(Builder &b) {
     return rth_set_roots(s, wl, ll);
 }
 
+// main.rs:524-683, scene_cornell_box_smoke: defined in the reference but called by no `Scene` variant (it also returns no
+// `lights`).  Kept for the one thing only it has: ConstantMedium over a boundary that is not a sphere (constant_medium.rs:52-58).
+// `lights` = its light rectangle, as scene_cornell_box does; the light is not wrapped in FlipFace there (main.rs:626-633).
+int build_cornell_box_smoke(Builder &b) {
+    rth_scene *s = b.s;
+    int red = b.lambert(0.65f, 0.05f, 0.05f);
+    int white = b.lambert(0.73f, 0.73f, 0.73f);
+    int green = b.lambert(0.12f, 0.45f, 0.15f);
+    std::vector<int32_t> world;
+    world.push_back(rth_add_rect(s, RTG_YZ_RECT, 0, 555, 0, 555, 555, green));
+    world.push_back(rth_add_rect(s, RTG_YZ_RECT, 0, 555, 0, 555, 0, red));
+    world.push_back(rth_add_rect(s, RTG_XZ_RECT, 0, 555, 0, 555, 0, white));
+    world.push_back(rth_add_rect(s, RTG_XZ_RECT, 0, 555, 0, 555, 555, white));
+    world.push_back(rth_add_rect(s, RTG_XY_RECT, 0, 555, 0, 555, 555, white));
+    world.push_back(rth_add_rect(s, RTG_XZ_RECT, 113, 443, 127, 432, 554, b.light(7, 7, 7)));
+    const float p0[3] = {0, 0, 0}, p1[3] = {165, 330, 165}, off1[3] = {265, 0, 295};
+    int box1 = rth_add_translate(s, rth_add_rotate_y(s, rth_add_block(s, p0, p1, white), 15.0f), off1);
+    world.push_back(rth_add_constant_medium(s, box1, rth_add_solid_texture(s, 0, 0, 0), 0.01f));     // from_colored_object, constant_medium.rs:28-38
+    const float q1[3] = {165, 165, 165}, off2[3] = {130, 0, 65};
+    int box2 = rth_add_translate(s, rth_add_rotate_y(s, rth_add_block(s, p0, q1, white), -18.0f), off2);
+    world.push_back(rth_add_constant_medium(s, box2, rth_add_solid_texture(s, 1, 1, 1), 0.01f));
+    int32_t l = rth_add_rect(s, RTG_XZ_RECT, 113, 443, 127, 432, 554, b.light(0, 0, 0));
+    int wl = rth_add_list(s, world.data(), (int)world.size());
+    int ll = rth_add_list(s, &l, 1);
+    return rth_set_roots(s, wl, ll);
+}
+
 // main.rs:685-828
 int build_final_chapter2(Builder &b, const rth_scene_assets *assets, uint32_t seed) {
     rth_scene *s = b.s;
@@ -886,6 +913,7 @@ int rth_build_scene(rth_scene *s, const char *name, uint32_t seed, const rth_sce
     std::string n(name);
     if (n == "RandomWorld") return build_random_world(b);
     if (n == "CornellBox") return build_cornell_box(b);
+    if (n == "CornellBoxSmoke") return build_cornell_box_smoke(b);
     if (n == "Chapter2Final") return build_final_chapter2(b, assets, seed);
     if (n == "MeshTest") return build_mesh_test(b, assets);
     if (n == "TwoSpheres") return build_two_spheres(b);

@@ -673,14 +673,37 @@ RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_
 
 // ConstantMedium::hit (constant_medium.rs:46-94) for a sphere boundary.  Draws random_real()
 // exactly when the reference does.
+// boundary.hit() of a medium whose boundary is not a plain sphere: the boundary's leaves are slots [first, first + count)
+// (a Block's six sides, a rectangle, a sphere; under Translate / RotateY) and the hit is HittableList::hit's fold over them,
+// literally: the later candidate replaces the kept one unless kept.t < t (hittable_list.rs:43-49; block.rs:111-113).
+template <bool STATS>
+RT_DEV bool boundary_hit(const DScene &sc, uint32_t first, uint32_t count, const Ray &r, float t_min, float t_max, float *t_out, Counters &cnt) {
+    bool have = false;
+    float kept = 0.0f;
+    for (uint32_t i = 0; i < count; ++i) {
+        float t; int32_t id;
+        if (!slot_hit<STATS, EXT_NONE>(sc, first + i, r, t_min, t_max, &t, &id, cnt)) continue;
+        if (!have || !(kept < t)) kept = t;
+        have = true;
+    }
+    *t_out = kept;
+    return have;
+}
+
 template <bool STATS>
 RT_DEV bool medium_hit(const DScene &sc, uint32_t m, const Ray &r, float t_min, float t_max, rts::Rng &rng, float *t_out, Counters &cnt) {
     float4 a = sc.media[2 * m], b = sc.media[2 * m + 1];
     if (STATS) cnt.medium_tests += 1;
     V3 c = v3(a.x, a.y, a.z);
     float t1, t2;
+    if (f2i(b.w) == 1) {     // general boundary (rt_api.h medium record)
+        const uint32_t first = (uint32_t)f2i(a.x), count = (uint32_t)f2i(a.y);
+        if (!boundary_hit<STATS>(sc, first, count, r, -RT_F32_MAX, RT_F32_MAX, &t1, cnt)) return false;
+        if (!boundary_hit<STATS>(sc, first, count, r, t1 + 0.0001f, RT_F32_MAX, &t2, cnt)) return false;
+    } else {
     if (!sphere_roots(c, a.w, r, -RT_F32_MAX, RT_F32_MAX, &t1)) return false;
     if (!sphere_roots(c, a.w, r, t1 + 0.0001f, RT_F32_MAX, &t2)) return false;
+    }
     if (t1 < t_min) t1 = t_min;
     if (t2 > t_max) t2 = t_max;
     if (t1 >= t2) return false;
@@ -1298,7 +1321,8 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
             float4 ma = sc.media[2 * m];
             float t1;
             V3 c = v3(ma.x, ma.y, ma.z);
-            if (sphere_roots(c, ma.w, ps.ray, -RT_F32_MAX, RT_F32_MAX, &t1)) sphere_uv((ps.ray.at(t1) - c) / ma.w, &rec.u, &rec.v);
+            // (a general boundary with a texture that reads u, v is refused at upload)
+            if (f2i(mb.w) != 1 && sphere_roots(c, ma.w, ps.ray, -RT_F32_MAX, RT_F32_MAX, &t1)) sphere_uv((ps.ray.at(t1) - c) / ma.w, &rec.u, &rec.v);
         }
     } else {
         int mat = f2i(sc.slots[4 * (size_t)best.slot + 1].y);

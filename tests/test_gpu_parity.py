@@ -85,7 +85,8 @@ def compare_images(rt, gpu, oracle, params, camera, sampler, **kw):
 
 @pytest.mark.parametrize("name,width,spp,n_rays", [("C1", 240, 9, 1 << 16), ("C2", 96, 16, 1 << 16), ("C3", 96, 16, 1 << 16),
                                                    ("C4", 64, 4, 1 << 13), ("GP", 96, 16, 1 << 16), ("BLOCKS", 96, 16, 1 << 16),
-                                                   ("TWO", 64, 9, 1 << 12), ("PERLIN", 96, 9, 1 << 14), ("LIGHT", 64, 16, 1 << 14), ("EARTH", 64, 4, 1 << 12)])
+                                                   ("TWO", 64, 9, 1 << 12), ("PERLIN", 96, 9, 1 << 14), ("LIGHT", 64, 16, 1 << 14), ("EARTH", 64, 4, 1 << 12),
+                                                   ("SMOKE", 96, 16, 1 << 14)])   # ConstantMedium over Translate(RotateY(Block)) boundaries
 def test_image_and_first_hit_small(rt, gpu, name, width, spp, n_rays):
     extra = {"mesh_grid": 1} if name == "C4" else {}
     scene, params, camera, sampler = rt.configs.build(name, image_width=width, samples_per_pixel=spp, **extra)

@@ -343,6 +343,28 @@ def test_constructors_that_take_what_the_reference_objects_hold(rt):
     assert np.array_equal(other.nodes().view(np.uint32), flat.nodes().view(np.uint32))
 
 
+def test_constant_medium_over_a_block_boundary(rt):
+    """scene_cornell_box_smoke (main.rs:524-683): the boundaries' 2 x 6 sides become slots behind the always-list that only the
+    media records refer to; they take no primitive id; what the flattener cannot express is refused."""
+    s = rt.host.Scene.build("CornellBoxSmoke")
+    flat = s.flatten()                                                    # keeps the arrays behind desc alive
+    d = flat.desc
+    assert (d.n_slots, d.always_begin, d.always_count, d.n_media, d.n_prims, d.n_rect_slots) == (18, 0, 6, 2, 8, 6)
+    med = np.ctypeslib.as_array(d.media, (2, 8)).copy()
+    assert med.view(np.int32)[:, [0, 1, 6, 7]].tolist() == [[6, 6, 6, 1], [12, 6, 7, 1]] and list(med[:, 4]) == [-100.0, -100.0]
+    slots = np.ctypeslib.as_array(d.slots, (18, 16)).copy()
+    assert (slots[6:, 6].view(np.int32) == -1).all() and ((slots[6:, 4].view(np.int32) >> 8) > 0).all()     # no id, all under a transform
+    with pytest.raises(rt.RtError) as e:                                  # the device build re-orders the head of the slot array only
+        s.flatten(device_bvh=True)
+    assert e.value.status == -5
+    x = rt.host.Scene()
+    m = x.lambertian(x.solid(1, 1, 1))
+    fog = x.constant_medium(x.cylinder(1.0, 0.0, 1.0, 6.2831855, m), x.solid(1, 1, 1), 0.1)
+    x.set_roots(x.hittable_list([fog]), x.hittable_list([x.sphere((0, 9, 0), 1, m)]))
+    with pytest.raises(rt.RtError):
+        x.flatten()
+
+
 def read_glb_positions(path):
     d = open(path, "rb").read()
     jlen = struct.unpack("<I", d[12:16])[0]
