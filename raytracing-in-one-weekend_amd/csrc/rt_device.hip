@@ -34,7 +34,7 @@ struct rt_ctx {
     bool bvh_has_general_xform = false;   // some slot under a general Transform sits in a BVH leaf
     int features = EXT_ALL;               // EXT_* bits the uploaded scene needs (rt_kernels.h); picks the kernel set
     float bvh_build_ms = 0.0f;
-    unsigned long long *d_stats = nullptr;  // 64 counters
+    unsigned long long *d_stats = nullptr;  // 128 words: counters + region timers of a render, the tail kernel's own timers from word 64 (development builds)
     hipDeviceProp_t prop{};
     // wavefront workspace (grown on demand, kept until rt_destroy)
     void *wf_pool = nullptr;      size_t wf_pool_entries = 0;   // 2 buffers x entries x 72 B
@@ -274,17 +274,20 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     }
     const bool debug = getenv("RT_DEBUG") != nullptr;
     unsigned long long *d_stats = (STATS || kTimers) ? ctx->d_stats : nullptr;
-    if (STATS || kTimers) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 64 * sizeof(unsigned long long), stream));
+    if (STATS || kTimers) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 128 * sizeof(unsigned long long), stream));
     // the tail kernel (rt_wavefront.h): finishes the last RT_WF_TAIL paths of a batch in one launch; 0 = never.  Default: on for
     // scenes without a BVH walk (measured on MI355X, 32768 against 0: C2 at 16 / 64 / 1000 spp +18 / +8 / +1 %), off with one:
     // there a bounce costs a lone wave as much as an iteration costs the pipeline (C4 at 4 spp +22 %, but C1 at 10 spp, whose last
     // paths rattle inside glass spheres for 40 bounces, -23 %).
     auto *const tail_kernel = K.tail;
-    const uint32_t tail_max = (uint32_t)env_size("RT_WF_TAIL", has_bvh ? 0 : 32768, 0, 1u << 20);
-    unsigned tail_nb = (tail_max + 4095u) / 4096u;                       // one lane per path: 64 shards x tail_nb waves
-    if (tail_nb > trav_blocks / 16u) tail_nb = trav_blocks / 16u;        // its lanes share the pipeline's stack overflow area
-    if (tail_nb < 1u) tail_nb = 1u;
-    const size_t tail_lds = (size_t)lds_depth * 64 * sizeof(StackEntry);
+    const uint32_t tail_max = (uint32_t)env_size("RT_WF_TAIL", 131072, 0, 1u << 20);
+    const int tail_every = (int)env_size("RT_WF_TAIL_EVERY", 2, 1, 16);   // iterations between two looks
+    unsigned tail_waves = tail_max / 64u + RT_WF_SHARDS;                 // one lane per path, one wave per set of 64 (a shard's last set may be ragged)
+    if (tail_waves > trav_blocks * 4u) tail_waves = trav_blocks * 4u;    // its lanes share the pipeline's stack overflow area
+    tail_waves = (tail_waves + 3u) / 4u * 4u;
+    const size_t tail_blk_env = env_size("RT_WF_TAIL_BLOCK", 256, 64, 256);
+    const unsigned tail_blk = tail_blk_env >= 256 ? 256u : tail_blk_env >= 128 ? 128u : 64u;   // threads per workgroup (its waves are independent)
+    const size_t tail_lds = (size_t)lds_depth * tail_blk * sizeof(StackEntry);
     const int tail_group = (int)env_size("RT_WF_TAIL_GROUP", 4, 1, 16);   // iterations enqueued at a time once every item is out
 
     struct Pipe {
@@ -376,8 +379,8 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                                        ctx->wf_samples, d_stats, d_rays);
                     hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, nxt, P.ctr, it,
                                        ctx->wf_samples, P.d_status, d_stats, d_rays);
-                    if (tail_max && (k & 3) == 3)
-                        hipLaunchKernelGGL(tail_kernel, dim3(RT_WF_SHARDS * tail_nb), dim3(64), tail_lds, P.s, ctx->sc, P.w, nxt, P.ctr, it + 1u,
+                    if (tail_max && (int)(it % (uint32_t)tail_every) == tail_every - 1)
+                        hipLaunchKernelGGL(tail_kernel, dim3(tail_waves * 64u / tail_blk), dim3(tail_blk), tail_lds, P.s, ctx->sc, P.w, nxt, P.ctr, it + 1u,
                                            tail_max, lds_depth, P.ovf, ctx->wf_samples, P.d_status, d_stats, d_rays);
                 }
                 HIP_TRY(ctx, hipGetLastError());
@@ -396,13 +399,18 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         HIP_TRY(ctx, hipGetLastError());
     }
     if (kTimers && !STATS) {   // development build: print where the waves' cycles went
-        unsigned long long h[64];
+        unsigned long long h[128];
         HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
         fprintf(stderr, "[rt-turns] %llu\n", h[RT_STAT_WORDS]);
         fprintf(stderr, "[rt-regions]");
         for (int i = 0; i < RT_N_REGIONS; ++i) fprintf(stderr, " %llu", h[RT_STAT_WORDS + 1 + i]);
         fprintf(stderr, "\n");
+        if (h[64 + RT_STAT_WORDS]) {   // the tail kernel ran: its slowest wave (cycles), and the sums over its waves by region
+            fprintf(stderr, "[rt-tail-slowest-wave-cycles] %llu\n[rt-tail-regions]", h[64 + RT_STAT_WORDS]);
+            for (int i = 0; i < RT_N_REGIONS; ++i) fprintf(stderr, " %llu", h[64 + RT_STAT_WORDS + 1 + i]);
+            fprintf(stderr, "\n");
+        }
     }
     return RT_OK;
 }
@@ -441,7 +449,7 @@ int rt_create(int device_id, rt_ctx **out) {
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_stats, 64 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_stats, 128 * sizeof(unsigned long long));
     if (e == hipSuccess && device_id < kMaxDevices) {   // this device's copy of the static scratch array (device_id is current)
         void *p = nullptr;
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch));

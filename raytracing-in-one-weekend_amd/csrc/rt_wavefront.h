@@ -476,23 +476,35 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
 // functions in the same order, hence the same bits — parks the samples and marks the entries dead, so the next
 // iteration finds an empty pool.  One wave per block: a block's waves would only wait for each other.
 template <bool STATS, int EXT>
-__global__ void __launch_bounds__(64) wf_tail_kernel(DScene sc, WfArgs w, PathQ q, const WfCounters *ctr, uint32_t it, uint32_t tail_max,
+__global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ q, const WfCounters *ctr, uint32_t it, uint32_t tail_max,
                                                      uint32_t lds_depth, StackEntry *ovf, float4 *__restrict__ samples, uint32_t *status,
                                                      unsigned long long *stats, uint32_t *pixel_rays) {
     extern __shared__ StackEntry lds_stack[];
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wpb = blockDim.x >> 6;
+    const uint32_t gw = blockIdx.x * wpb + (threadIdx.x >> 6), n_gw = gridDim.x * wpb;   // this wave among all waves of the launch
     const WfCounters *c = ctr + (it % RT_WF_RING);      // written by the generate before this launch, by nobody during it
-    uint32_t live = wave_sum(c->sh[lane].count_in);
+    const uint32_t my_count = c->sh[lane].count_in;     // lane s looks at shard s
+    uint32_t live = wave_sum(my_count);
     live = (uint32_t)__shfl((int)live, 0, 64);
     if (live == 0u || live > tail_max || c->sh[0].item_head != w.n_items) return;      // the same answer in every block
-    if (blockIdx.x == 0 && lane == 0) status[0] = 0u;   // what the next generate would report
-    const uint32_t shard = blockIdx.x % RT_WF_SHARDS, b = blockIdx.x / RT_WF_SHARDS, nb = gridDim.x / RT_WF_SHARDS;
-    const uint32_t n = c->sh[shard].count_in;
-    const Stack stack{(LdsStackPtr)lds_stack + lane, blockDim.x, lds_depth, ovf ? ovf + (size_t)blockIdx.x * blockDim.x + lane : nullptr, gridDim.x * blockDim.x};
+    if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 0u;   // what the next generate would report
+    // The live paths sit unevenly in the shards (a shard holds neighbouring tiles: sky dies at once, a glass sphere lives to the
+    // depth limit), so the sets of 64 paths are numbered through all shards and dealt to the waves of the launch round-robin.
+    uint32_t sets_incl = (my_count + 63u) >> 6;          // inclusive prefix sum of the shards' set counts
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)sets_incl, o, 64);
+        if (lane >= o) sets_incl += up;
+    }
+    const uint32_t n_sets = (uint32_t)__shfl((int)sets_incl, 63, 64);
+    const Stack stack{(LdsStackPtr)lds_stack + threadIdx.x, blockDim.x, lds_depth, ovf ? ovf + (size_t)blockIdx.x * blockDim.x + threadIdx.x : nullptr, gridDim.x * blockDim.x};
     const V3 background = v3(w.a.bg[0], w.a.bg[1], w.a.bg[2]);
     const float T_MIN = 0.001f;
     Counters cnt{};
-    for (uint32_t off = b * 64u; off < n; off += nb * 64u) {
+    const unsigned long long tail_t0 = (kTimers && !STATS) ? __builtin_readcyclecounter() : 0ull;
+    for (uint32_t set = gw; set < n_sets; set += n_gw) {
+        const uint32_t shard = (uint32_t)__popcll(__ballot(sets_incl <= set));          // first shard whose prefix exceeds `set`
+        const uint32_t first_set = shard ? (uint32_t)__shfl((int)sets_incl, (int)shard - 1, 64) : 0u;
+        const uint32_t n = (uint32_t)__shfl((int)my_count, (int)shard, 64), off = (set - first_set) * 64u;
         const uint32_t i = shard * w.cap + off + lane;
         bool alive = false, walk = false;
         WfPath p;
@@ -571,7 +583,13 @@ __global__ void __launch_bounds__(64) wf_tail_kernel(DScene sc, WfArgs w, PathQ 
             RG_END(RG_BEGIN_ALL);
         }
     }
-    if (STATS || kTimers) flush_counters<STATS>(cnt, 0u, stats);
+    if (kTimers && !STATS) {   // development builds: the kernel's own timers apart from the pipeline's (stats + 64)
+        const unsigned long long dt = __builtin_readcyclecounter() - tail_t0;
+        if (lane == 0) atomicMax(&stats[64 + RT_STAT_WORDS], dt);
+        flush_counters<STATS>(cnt, 0u, stats + 64);
+        return;
+    }
+    if (STATS) flush_counters<STATS>(cnt, 0u, stats);
 }
 
 /* ------------------------------------------------------------------ fold */

@@ -59,8 +59,10 @@ def test_reference_image_matches_the_oracle(rt, gpu, book2):
     {"RT_WF_POOL_LOG2": 15, "RT_WF_PIPES": 1},
     {"RT_WF_LDS_DEPTH": 3},                        # almost the whole traversal stack in the HBM overflow area
     {"RT_WF_SAMPLES_MB": 1},                       # 64 Ki samples per batch -> several batches, several folds
-    {"RT_WF_TAIL": 32768},                         # the last paths finished by wf_tail_kernel (off by default with a BVH)
-    {"RT_WF_TAIL": 1000000},                       # ... everything that is left once all items are out
+    {"RT_WF_TAIL": 0},                             # no wf_tail_kernel: the last paths go through the pipeline to their end
+    {"RT_WF_TAIL": 32768, "RT_WF_TAIL_BLOCK": 64, "RT_WF_TAIL_EVERY": 1},   # (default: 131072 paths, 256 threads, every 2nd iteration)
+    {"RT_WF_TAIL": 256, "RT_WF_TAIL_BLOCK": 128, "RT_WF_TAIL_EVERY": 3},    # ... a launch of 68 waves
+    {"RT_WF_TAIL": 1000000},                       # ... everything that is left once all items are out: its waves take several sets each
     {"RT_WF_TAIL": 3000, "RT_WF_LDS_DEPTH": 3, "RT_WF_PIPES": 1},   # ... with its stack in the overflow area
 ])
 def test_image_is_independent_of_the_pipeline_geometry(gpu, book2, env):
@@ -95,7 +97,7 @@ def test_counting_variant_traces_the_same_paths(gpu, book2):
 
 
 def test_tail_kernel_changes_no_bit(rt, gpu, book2):
-    # scenes without a BVH walk (Cornell: 13 leaves, flat scan) finish their last paths in wf_tail_kernel by default
+    # every scene finishes its last paths in wf_tail_kernel by default; here one without a BVH walk (Cornell: 13 leaves, flat scan)
     scene, params, camera, sampler = rt.configs.build("C2", image_width=64, samples_per_pixel=36)
     gpu.upload_scene(scene.flatten())
     gpu.upload_sampler(sampler)

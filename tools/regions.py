@@ -41,3 +41,12 @@ print("      inside lambertian:"); [line(k, "      ") for k in ("TEXTURE", "L_LI
 print("   inside begin_trace:"); [line(k, "   ") for k in ("B_MEDIA", "B_ALWAYS")]
 print("-- traverse kernel"); [line(k) for k in top_t]
 print("-- generate: camera"); line("CAMERA")
+
+# the tail kernel's own timers (sums over its waves), if it ran
+tl = [l for l in err.splitlines() if l.startswith("[rt-tail-regions]")]
+if tl:
+    tr = dict(zip(names, [int(x) for x in tl[-1].split()[1:]]))
+    slow = [int(l.split()[1]) for l in err.splitlines() if l.startswith("[rt-tail-slowest-wave-cycles]")][-1]
+    print("-- tail kernel: slowest wave %d cycles; sums over its waves (wave-cycles):" % slow)
+    for k in ("TRAV_ALL", "NODE", "LEAF", "SHADE_ALL", "RECORD", "METAL", "DIEL", "LAMBERT", "TEXTURE", "L_LIGHTS", "L_COSINE", "L_PDF", "BEGIN_ALL"):
+        print("   %-10s %12d" % (k, tr[k]))
