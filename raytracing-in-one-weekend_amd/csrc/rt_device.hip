@@ -288,7 +288,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     const size_t tail_blk_env = env_size("RT_WF_TAIL_BLOCK", 256, 64, 256);
     const unsigned tail_blk = tail_blk_env >= 256 ? 256u : tail_blk_env >= 128 ? 128u : 64u;   // threads per workgroup (its waves are independent)
     const size_t tail_lds = (size_t)lds_depth * tail_blk * sizeof(StackEntry);
-    const int tail_group = (int)env_size("RT_WF_TAIL_GROUP", 4, 1, 16);   // iterations enqueued at a time once every item is out
+    const int tail_group = (int)env_size("RT_WF_TAIL_GROUP", 2, 1, 16);   // iterations enqueued at a time once every item is out
 
     struct Pipe {
         hipStream_t s;
@@ -337,13 +337,39 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             if (w.pool > pool_want) w.pool = (uint32_t)pool_want;
             w.cap = w.pool / RT_WF_SHARDS;
             P.chunks = w.cap / 256u;
-            P.items_out = false;
+            // a batch that fits the pool is handed out whole by the first generate: the pool only shrinks from the start
+            P.items_out = w.n_items <= w.pool;
             P.trav_blocks = trav_blocks;
             HIP_TRY(ctx, hipMemsetAsync(P.ctr, 0, (RT_WF_RING + 1) * sizeof(WfCounters), P.s));
-            P.it = 0; P.groups = 0; P.drained = false; P.it_end = 0xffffffffu;
+            P.it = 0; P.groups = 0; P.drained = false;
+            P.it_end = P.items_out ? (uint32_t)(a.max_depth > 0 ? a.max_depth : 0) + 1u : 0xffffffffu;
             hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, w, P.Q[1], P.ctr, P.it,
                                ctx->wf_samples, P.d_status, d_stats, d_rays);
         }
+        auto launch_tail = [&](Pipe &P) {   // on the pool buffer the generate of iteration P.it has just completed
+            hipLaunchKernelGGL(tail_kernel, dim3(tail_waves * 64u / tail_blk), dim3(tail_blk), tail_lds, P.s, ctx->sc, P.w, P.Q[(P.it + 1u) & 1u], P.ctr,
+                               P.it + 1u, tail_max, lds_depth, P.ovf, ctx->wf_samples, P.d_status, d_stats, d_rays);
+        };
+        auto enqueue_iteration = [&](Pipe &P) {
+            if (P.items_out && P.it >= P.it_end) return;   // every path has run out of depth by then: nothing left to enqueue
+            const uint32_t it = ++P.it;
+            const PathQ &cur = P.Q[it & 1], &nxt = P.Q[(it + 1) & 1];
+            if (has_bvh) hipLaunchKernelGGL(trav_kernel, dim3(P.trav_blocks), dim3(256), lds, P.s, ctx->sc, cur, P.ctr, it, P.w.cap,
+                                            lds_depth, P.ovf, d_stats);
+            hipLaunchKernelGGL(K.shade, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
+                               ctx->wf_samples, d_stats, d_rays);
+            hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, nxt, P.ctr, it,
+                               ctx->wf_samples, P.d_status, d_stats, d_rays);
+            if (tail_max && (int)(it % (uint32_t)tail_every) == tail_every - 1) launch_tail(P);
+        };
+        // groups of 8 iterations while items are handed out; 2 in the tail, where what is enqueued after the pool has drained
+        // (the host learns of it a group late) is pure waste
+        auto group_size = [&](const Pipe &P) { return P.items_out ? tail_group : 8; };
+        // the first group of every pipeline, iteration by iteration in turn: enqueued one pipeline after the other, the second
+        // pipeline would start a whole group of launches late
+        for (int k = 0; k < 8; ++k)
+            for (int q = 0; q < n_pipes; ++q)
+                if (k < group_size(pipe[q])) enqueue_iteration(pipe[q]);
         for (int live = n_pipes; live > 0;) {
             for (int q = 0; q < n_pipes; ++q) {
                 Pipe &P = pipe[q];
@@ -365,24 +391,16 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                         P.chunks = need < 1u ? 1u : (need < P.w.cap / 256u ? need : P.w.cap / 256u);
                         const unsigned tb = P.chunks * RT_WF_SHARDS;
                         P.trav_blocks = tb < trav_blocks ? tb : trav_blocks;
+                        if (tail_max && hs[0] <= tail_max) {   // what is left fits one tail launch (and only shrinks): that launch ends the batch
+                            launch_tail(P);
+                            HIP_TRY(ctx, hipGetLastError());
+                            P.drained = true; --live;
+                            continue;
+                        }
                     }
                 }
-                // groups of 8 iterations while items are handed out; 4 in the tail, where what is enqueued after the pool has
-                // drained (the host learns of it a group late) is pure waste
-                for (int k = 0, gsize = P.items_out ? tail_group : 8; k < gsize; ++k) {
-                    if (P.items_out && P.it >= P.it_end) break;   // every path has run out of depth by then: nothing left to enqueue
-                    const uint32_t it = ++P.it;
-                    const PathQ &cur = P.Q[it & 1], &nxt = P.Q[(it + 1) & 1];
-                    if (has_bvh) hipLaunchKernelGGL(trav_kernel, dim3(P.trav_blocks), dim3(256), lds, P.s, ctx->sc, cur, P.ctr, it, P.w.cap,
-                                                    lds_depth, P.ovf, d_stats);
-                    hipLaunchKernelGGL(K.shade, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
-                                       ctx->wf_samples, d_stats, d_rays);
-                    hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, nxt, P.ctr, it,
-                                       ctx->wf_samples, P.d_status, d_stats, d_rays);
-                    if (tail_max && (int)(it % (uint32_t)tail_every) == tail_every - 1)
-                        hipLaunchKernelGGL(tail_kernel, dim3(tail_waves * 64u / tail_blk), dim3(tail_blk), tail_lds, P.s, ctx->sc, P.w, nxt, P.ctr, it + 1u,
-                                           tail_max, lds_depth, P.ovf, ctx->wf_samples, P.d_status, d_stats, d_rays);
-                }
+                if (group >= 1)      // (group 0 was enqueued above)
+                    for (int k = 0, gsize = group_size(P); k < gsize; ++k) enqueue_iteration(P);
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipMemcpyAsync(P.h_status + 4 * (group & 1), P.d_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, P.s));
                 HIP_TRY(ctx, hipEventRecord(ctx->wf_event[q][group & 1], P.s));
