@@ -82,13 +82,41 @@ int rth_set_roots(rth_scene *s, int world_list, int lights_list);
 
 /* ------------------------------------------------------------------ glTF import */
 typedef struct rth_geometry rth_geometry;
-/* ImportedGeometry::import_from_file for a .glb (geometry only: positions, normals, uvs,
- * indices, nodes; children before the node's own mesh; the importer's quaternion/matrix
- * quirks of geometry_import.rs:314-329 are reproduced). */
+/* ImportedGeometry::import_from_file for a .glb (positions, normals, uvs, indices, nodes; children
+ * before the node's own mesh; the importer's quaternion/matrix quirks of geometry_import.rs:314-329
+ * are reproduced; materials, colours, tangents and images: see below). */
 int  rth_geometry_import_glb(const char *path, rth_geometry **out);
 void rth_geometry_free(rth_geometry *g);
 void rth_geometry_view(const rth_geometry *g, const rtg_vertex **verts, uint32_t *n_verts, const uint32_t **indices,
                        uint32_t *n_indices, const rtg_mesh_node **nodes, uint32_t *n_nodes);
+
+/* The PBR side of the import (geometry_import.rs:15-24, 47-55, 172-304).  The reference fills these tables and
+ * its renderer then never looks at them (triangle_mesh.rs:181, 238-239: the mesh is shaded with the one material it was given),
+ * so they cannot change an image; they are here so that a host that switches to this library finds what ImportedGeometry held.
+ * PbrMaterial, field for field (repr(C, align(16)): 32 bytes): */
+typedef struct rth_pbr_material {
+    float    base_color_factor[3];          /* baseColorFactor.xyz (alpha dropped, geometry_import.rs:291) */
+    float    metallic_factor, roughness_factor;
+    uint32_t base_color_texarray_id;        /* layer in the base-colour image list below, not the glTF image index */
+    uint32_t metallic_rough_texarray_id;
+    uint32_t normal_texarray_id;
+} rth_pbr_material;
+/* what GeometryVertex carries besides pos / normal / uv (geometry_import.rs:47-68); parallel to rth_geometry_view's vertices */
+typedef struct rth_vertex_attrs {
+    float    color[4];      /* COLOR_0 as rgba f32, default 0,0,0,1 */
+    float    tangent[4];    /* TANGENT, default 0,0,0,0 */
+    uint32_t pbr_buf_id;    /* index into the material table: the primitive's material, by NAME (geometry_import.rs:363-375) */
+} rth_vertex_attrs;
+void rth_geometry_pbr_materials(const rth_geometry *g, const rth_pbr_material **materials, uint32_t *n_materials);
+void rth_geometry_vertex_attrs(const rth_geometry *g, const rth_vertex_attrs **attrs, uint32_t *n_verts);
+/* gltf_mat_2_pbr_mat_mapping: material name -> index into the table, -1 if there is none of that name */
+int32_t rth_geometry_material_index(const rth_geometry *g, const char *name);
+/* pbr_base_color_images / pbr_metallic_roughness_images / pbr_normal_images (geometry_import.rs:114-142): kind 0 / 1 / 2.  The layers
+ * are the distinct source images of that kind in ascending glTF image index (sort + dedup, :225-263), decoded to RGBA8 (:465-486;
+ * rth_image_decode).  *width, *height are those of the kind's FIRST layer — for kind 2 of the first metallic-roughness layer, as the
+ * reference has it (:135).  layer_sizes (may be NULL) receives width, height per layer.  Pointers stay valid until rth_geometry_free. */
+int rth_geometry_pbr_images(const rth_geometry *g, int kind, uint32_t *width, uint32_t *height, uint32_t *n_layers,
+                            const uint8_t *const **rgba_layers, const uint32_t **layer_sizes);
 
 /* ------------------------------------------------------------------ the reference's scenes */
 typedef struct rth_image { int32_t width, height; const uint8_t *rgba; } rth_image;

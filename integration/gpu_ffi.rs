@@ -194,6 +194,16 @@ pub struct rtg_vertex { pub pos: [f32; 3], pub normal: [f32; 3], pub uv: [f32; 2
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct rtg_mesh_node { pub index_begin: u32, pub index_count: u32 }
+/// rth_pbr_material / rth_vertex_attrs (rt_host.h): PbrMaterial and the rest of GeometryVertex (geometry_import.rs:15-24, 47-55)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rth_pbr_material {
+    pub base_color_factor: [f32; 3], pub metallic_factor: f32, pub roughness_factor: f32,
+    pub base_color_texarray_id: u32, pub metallic_rough_texarray_id: u32, pub normal_texarray_id: u32,
+}
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rth_vertex_attrs { pub color: [f32; 4], pub tangent: [f32; 4], pub pbr_buf_id: u32 }
 #[repr(C)]
 pub struct rtg_perlin { pub ranvec: [[f32; 3]; 256], pub perm_x: [i32; 256], pub perm_y: [i32; 256], pub perm_z: [i32; 256] }
 
@@ -309,6 +319,11 @@ extern "C" {
     pub fn rth_geometry_free(g: *mut rth_geometry);
     pub fn rth_geometry_view(g: *const rth_geometry, verts: *mut *const rtg_vertex, n_verts: *mut u32, indices: *mut *const u32, n_indices: *mut u32,
                              nodes: *mut *const rtg_mesh_node, n_nodes: *mut u32);
+    pub fn rth_geometry_pbr_materials(g: *const rth_geometry, materials: *mut *const rth_pbr_material, n_materials: *mut u32);
+    pub fn rth_geometry_vertex_attrs(g: *const rth_geometry, attrs: *mut *const rth_vertex_attrs, n_verts: *mut u32);
+    pub fn rth_geometry_material_index(g: *const rth_geometry, name: *const c_char) -> i32;
+    pub fn rth_geometry_pbr_images(g: *const rth_geometry, kind: c_int, width: *mut u32, height: *mut u32, n_layers: *mut u32,
+                                   rgba_layers: *mut *const *const u8, layer_sizes: *mut *const u32) -> c_int;
     pub fn rth_mat4_mul(a: *const f32, b: *const f32, out: *mut f32);
     pub fn rth_mat4_invert(m: *const f32, out: *mut f32) -> c_int;
     pub fn rth_mat4_transpose(m: *const f32, out: *mut f32);

@@ -119,6 +119,15 @@ class rtg_vertex(C.Structure):
     _fields_ = [("pos", C.c_float * 3), ("normal", C.c_float * 3), ("uv", C.c_float * 2)]
 
 
+class rth_pbr_material(C.Structure):     # include/rt_host.h; PbrMaterial of geometry_import.rs:15-24
+    _fields_ = [("base_color_factor", C.c_float * 3), ("metallic_factor", C.c_float), ("roughness_factor", C.c_float),
+                ("base_color_texarray_id", C.c_uint32), ("metallic_rough_texarray_id", C.c_uint32), ("normal_texarray_id", C.c_uint32)]
+
+
+class rth_vertex_attrs(C.Structure):
+    _fields_ = [("color", C.c_float * 4), ("tangent", C.c_float * 4), ("pbr_buf_id", C.c_uint32)]
+
+
 class rtg_mesh_node(C.Structure):
     _fields_ = [("index_begin", C.c_uint32), ("index_count", C.c_uint32)]
 
@@ -175,6 +184,7 @@ HOST_SYMBOLS = [
     "rth_add_paraboloid", "rth_add_hyperboloid", "rth_flatten_opts", "rth_write_png_rgb8", "rth_checkpoint_save",
     "rth_checkpoint_load", "rth_image_decode", "rth_image_decode_file", "rth_image_free", "rth_add_rotate_y_sincos",
     "rth_mat4_transpose", "rth_color_from_u32", "rth_rgba8_to_u32", "rth_rgba8_from_html",
+    "rth_geometry_pbr_materials", "rth_geometry_vertex_attrs", "rth_geometry_material_index", "rth_geometry_pbr_images",
 ]
 
 HIP_SYMBOLS = [
@@ -240,6 +250,13 @@ def host_lib():
     L.rth_geometry_view.argtypes = [vp, C.POINTER(C.POINTER(rtg_vertex)), c_u32_p, C.POINTER(c_u32_p), c_u32_p,
                                     C.POINTER(C.POINTER(rtg_mesh_node)), c_u32_p]
     L.rth_geometry_view.restype = None
+    L.rth_geometry_pbr_materials.argtypes = [vp, C.POINTER(C.POINTER(rth_pbr_material)), c_u32_p]
+    L.rth_geometry_pbr_materials.restype = None
+    L.rth_geometry_vertex_attrs.argtypes = [vp, C.POINTER(C.POINTER(rth_vertex_attrs)), c_u32_p]
+    L.rth_geometry_vertex_attrs.restype = None
+    L.rth_geometry_material_index.argtypes = [vp, C.c_char_p]
+    L.rth_geometry_material_index.restype = C.c_int32
+    L.rth_geometry_pbr_images.argtypes = [vp, C.c_int, c_u32_p, c_u32_p, c_u32_p, C.POINTER(C.POINTER(c_u8_p)), C.POINTER(c_u32_p)]
     L.rth_build_scene.argtypes = [vp, C.c_char_p, u32, C.POINTER(rth_scene_assets)]
     L.rth_config_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.rth_config_parse.argtypes = [C.c_char_p, C.POINTER(vp)]

@@ -282,7 +282,9 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     auto *const tail_kernel = K.tail;
     const uint32_t tail_max = (uint32_t)env_size("RT_WF_TAIL", 131072, 0, 1u << 20);
     const int tail_every = (int)env_size("RT_WF_TAIL_EVERY", 2, 1, 16);   // iterations between two looks
-    unsigned tail_waves = tail_max / 64u + RT_WF_SHARDS;                 // one lane per path, one wave per set of 64 (a shard's last set may be ragged)
+    const size_t tail_set_env = env_size("RT_WF_TAIL_SET", 64, 8, 64);
+    const uint32_t tail_set = tail_set_env >= 64 ? 64u : tail_set_env >= 32 ? 32u : tail_set_env >= 16 ? 16u : 8u;   // paths per wave
+    unsigned tail_waves = tail_max / tail_set + RT_WF_SHARDS;            // one lane per path, one wave per set (a shard's last set may be ragged)
     if (tail_waves > trav_blocks * 4u) tail_waves = trav_blocks * 4u;    // its lanes share the pipeline's stack overflow area
     tail_waves = (tail_waves + 3u) / 4u * 4u;
     const size_t tail_blk_env = env_size("RT_WF_TAIL_BLOCK", 256, 64, 256);
@@ -348,7 +350,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         }
         auto launch_tail = [&](Pipe &P) {   // on the pool buffer the generate of iteration P.it has just completed
             hipLaunchKernelGGL(tail_kernel, dim3(tail_waves * 64u / tail_blk), dim3(tail_blk), tail_lds, P.s, ctx->sc, P.w, P.Q[(P.it + 1u) & 1u], P.ctr,
-                               P.it + 1u, tail_max, lds_depth, P.ovf, ctx->wf_samples, P.d_status, d_stats, d_rays);
+                               P.it + 1u, tail_max, tail_set, lds_depth, P.ovf, ctx->wf_samples, P.d_status, d_stats, d_rays);
         };
         auto enqueue_iteration = [&](Pipe &P) {
             if (P.items_out && P.it >= P.it_end) return;   // every path has run out of depth by then: nothing left to enqueue

@@ -6,8 +6,10 @@
 // BIN chunk.  Kept on purpose: a TRS rotation [x,y,z,w] is read as [w,x,y,z]
 // (geometry_import.rs:325 + math/src/quat.rs:120-131) and a node `matrix` is copied
 // row-by-row although glTF stores it column-major (geometry_import.rs:316 + mat4.rs:279-313).
-// Images / PBR materials are not decoded: TriangleMesh shades with the single material it is
-// given (triangle_mesh.rs:238-239); the importer's material preconditions are still checked.
+// The PBR side (process_materials, geometry_import.rs:172-304; vertex colours, tangents and material ids, :385-425; the
+// embedded images as RGBA8, :459-486) is imported too, although TriangleMesh shades with the single material it is given
+// (triangle_mesh.rs:238-239) and nothing of it reaches an image.
+#include <algorithm>
 #include <fstream>
 #include <map>
 
@@ -116,6 +118,7 @@ struct Importer {
     const uint8_t *bin;
     size_t bin_len;
     Mesh &out;
+    rth_geometry &geo;
     std::string err;
 
     struct NodeRec { int parent; M4 transform; };
@@ -198,6 +201,13 @@ struct Importer {
             const J *mats = doc.get("materials"), *mi = prim.get("material");
             if (!mats || !mi || (size_t)mi->as_int() >= mats->arr.size() || !mats->arr[mi->as_int()].get("name"))
                 return fail("Materials without names are not supported chief ...");
+            // ... and it is found by NAME in the table process_materials made (:368-375); two materials of one name cannot exist (:268)
+            int material_index = -1;
+            {
+                const std::string &nm_ = mats->arr[mi->as_int()].get("name")->str;
+                for (size_t k = 0; k < geo.pbr_names.size(); ++k) if (geo.pbr_names[k] == nm_) { material_index = (int)k; break; }
+            }
+            if (material_index < 0) return fail("Fatal error: material not found in PBR materials buffer.");
             const J *attrs = prim.get("attributes");
             const J *pos = attrs ? attrs->get("POSITION") : nullptr;
             if (!pos) return fail("Missing positions attribute on mesh");
@@ -213,6 +223,10 @@ struct Importer {
                 o.pos[1] = matrix.at(1, 0) * v[0] + matrix.at(1, 1) * v[1] + matrix.at(1, 2) * v[2] + matrix.at(1, 3) * 1.0f;
                 o.pos[2] = matrix.at(2, 0) * v[0] + matrix.at(2, 1) * v[1] + matrix.at(2, 2) * v[2] + matrix.at(2, 3) * 1.0f;
                 out.verts.push_back(o);
+                rth_vertex_attrs x{};      // GeometryVertex::default (geometry_import.rs:57-68) + the primitive's material
+                x.color[3] = 1.0f;
+                x.pbr_buf_id = (uint32_t)material_index;
+                geo.vertex_attrs.push_back(x);
             }
             if (const J *nr = attrs->get("NORMAL")) {
                 if (!accessor(nr->as_int(), &a)) return false;
@@ -240,6 +254,26 @@ struct Importer {
                     else return fail("TEXCOORD_0 component type not supported");
                 }
             }
+            if (const J *tg = attrs->get("TANGENT")) {      // read_tangents: float VEC4 (:415-419)
+                if (!accessor(tg->as_int(), &a)) return false;
+                if (a.component != 5126 || a.ncomp != 4) return fail("TANGENT must be float VEC4");
+                for (size_t i = 0; i < a.count && vertex_start + i < out.verts.size(); ++i) memcpy(geo.vertex_attrs[vertex_start + i].tangent, a.base + i * a.stride, 16);
+            }
+            if (const J *cl = attrs->get("COLOR_0")) {      // read_colors(0).into_rgba_f32 (:421-425): RGB gets alpha 1, integers are normalised
+                if (!accessor(cl->as_int(), &a)) return false;
+                if (a.ncomp != 3 && a.ncomp != 4) return fail("COLOR_0 must be VEC3 or VEC4");
+                for (size_t i = 0; i < a.count && vertex_start + i < out.verts.size(); ++i) {
+                    float *d = geo.vertex_attrs[vertex_start + i].color;
+                    const uint8_t *sp = a.base + i * a.stride;
+                    d[3] = 1.0f;
+                    for (int c = 0; c < a.ncomp; ++c) {
+                        if (a.component == 5126) memcpy(&d[c], sp + 4 * c, 4);
+                        else if (a.component == 5121) d[c] = (float)sp[c] / 255.0f;
+                        else if (a.component == 5123) { uint16_t h; memcpy(&h, sp + 2 * c, 2); d[c] = (float)h / 65535.0f; }
+                        else return fail("COLOR_0 component type not supported");
+                    }
+                }
+            }
             const J *ind = prim.get("indices");
             if (!ind) return fail("Missing indices on mesh");
             if (!accessor(ind->as_int(), &a)) return false;
@@ -257,20 +291,91 @@ struct Importer {
         return true;
     }
 
-    // geometry_import.rs:172-201: every material needs a base-colour, a metallic-roughness and a
-    // normal texture, otherwise process_materials panics.
-    bool check_materials() {
+    // texture index -> image index (`.texture().source().index()`, geometry_import.rs:184-186)
+    bool texture_source(const J *tex_info, uint32_t *image) {
+        const J *textures = doc.get("textures"), *ti = tex_info ? tex_info->get("index") : nullptr;
+        if (!textures || !ti || ti->as_int() < 0 || (size_t)ti->as_int() >= textures->arr.size()) return fail("texture index out of range");
+        const J *src = textures->arr[ti->as_int()].get("source");
+        if (!src || src->as_int() < 0) return fail("texture without an image source");
+        *image = (uint32_t)src->as_int();
+        return true;
+    }
+
+    // process_materials (geometry_import.rs:172-304).  Every material needs a name, a base-colour, a metallic-roughness and a
+    // normal texture, otherwise the reference panics (:176-201).  Per kind the distinct source images, ascending, are the layers
+    // of a texture array (:225-263); a material stores the layer, not the image (:270-297).
+    bool process_materials() {
         const J *mats = doc.get("materials");
+        struct Def { std::string name; uint32_t src[3]; float base[4], metallic, roughness; };
+        std::vector<Def> defs;
         for (const J &m : mats ? mats->arr : std::vector<J>{}) {
             const J *pbr = m.get("pbrMetallicRoughness");
+            if (!m.get("name") || m.get("name")->kind != J::Str) return fail("Unnamed materials are not supported!");
             if (!pbr || !pbr->get("baseColorTexture") || !pbr->get("metallicRoughnessTexture") || !m.get("normalTexture"))
                 return fail("material lacks base colour / metallic-roughness / normal texture");
+            Def d{};
+            d.name = m.get("name")->str;
+            if (!texture_source(pbr->get("baseColorTexture"), &d.src[0]) || !texture_source(pbr->get("metallicRoughnessTexture"), &d.src[1]) ||
+                !texture_source(m.get("normalTexture"), &d.src[2])) return false;
+            d.base[0] = d.base[1] = d.base[2] = d.base[3] = 1.0f;      // glTF defaults: factor 1,1,1,1, metallic 1, roughness 1
+            if (const J *f = pbr->get("baseColorFactor")) if (f->arr.size() == 4) for (int i = 0; i < 4; ++i) d.base[i] = (float)f->arr[i].num;
+            d.metallic = pbr->get("metallicFactor") ? (float)pbr->get("metallicFactor")->num : 1.0f;
+            d.roughness = pbr->get("roughnessFactor") ? (float)pbr->get("roughnessFactor")->num : 1.0f;
+            defs.push_back(d);
+        }
+        for (int kind = 0; kind < 3; ++kind) {
+            std::vector<uint32_t> &l = geo.image_list[kind];
+            for (const Def &d : defs) l.push_back(d.src[kind]);
+            std::sort(l.begin(), l.end());
+            l.erase(std::unique(l.begin(), l.end()), l.end());
+        }
+        auto layer_of = [&](int kind, uint32_t image) {
+            const std::vector<uint32_t> &l = geo.image_list[kind];
+            return (uint32_t)(std::lower_bound(l.begin(), l.end(), image) - l.begin());
+        };
+        for (const Def &d : defs) {
+            for (const std::string &n : geo.pbr_names) if (n == d.name) return fail("two materials of one name");   // the assert of :268
+            rth_pbr_material m{};
+            m.base_color_factor[0] = d.base[0]; m.base_color_factor[1] = d.base[1]; m.base_color_factor[2] = d.base[2];
+            m.metallic_factor = d.metallic; m.roughness_factor = d.roughness;
+            m.base_color_texarray_id = layer_of(0, d.src[0]);
+            m.metallic_rough_texarray_id = layer_of(1, d.src[1]);
+            m.normal_texarray_id = layer_of(2, d.src[2]);
+            geo.pbr_materials.push_back(m);
+            geo.pbr_names.push_back(d.name);
         }
         return true;
     }
 
+    // gltf::import_slice decodes every image of the document; the reference then widens RGB8 to RGBA8 (geometry_import.rs:459-486).
+    // Here: the host library's own decoder, which gives RGBA8 for every format it reads (into_rgba8).  An image it cannot read (or
+    // one that lives in an external file: a .glb embeds its images) stays empty and fails only if a material list asks for it.
+    void decode_images() {
+        const J *imgs = doc.get("images"), *views = doc.get("bufferViews");
+        geo.images.resize(imgs ? imgs->arr.size() : 0);
+        for (size_t i = 0; i < geo.images.size(); ++i) {
+            const J *bv = imgs->arr[i].get("bufferView");
+            if (!bv || !views || bv->as_int() < 0 || (size_t)bv->as_int() >= views->arr.size()) continue;
+            const J &view = views->arr[bv->as_int()];
+            const size_t off = (size_t)(view.get("byteOffset") ? view.get("byteOffset")->num : 0), len = (size_t)(view.get("byteLength") ? view.get("byteLength")->num : 0);
+            if ((view.get("buffer") && view.get("buffer")->as_int(0) != 0) || !len || off + len > bin_len) continue;
+            int32_t w = 0, h = 0;
+            uint8_t *px = nullptr;
+            if (rth_image_decode(bin + off, len, &w, &h, &px) != RT_OK) continue;
+            geo.images[i].width = (uint32_t)w; geo.images[i].height = (uint32_t)h; geo.images[i].rgba = px;
+        }
+        for (int kind = 0; kind < 3; ++kind)
+            for (uint32_t image : geo.image_list[kind]) {
+                const bool have = image < geo.images.size() && geo.images[image].rgba;
+                geo.layer_ptrs[kind].push_back(have ? geo.images[image].rgba : nullptr);
+                geo.layer_sizes[kind].push_back(have ? geo.images[image].width : 0u);
+                geo.layer_sizes[kind].push_back(have ? geo.images[image].height : 0u);
+            }
+    }
+
     bool run() {
-        if (!check_materials()) return false;
+        if (!process_materials()) return false;
+        decode_images();
         const J *scenes = doc.get("scenes");
         for (const J &sc : scenes ? scenes->arr : std::vector<J>{})
             if (const J *ns = sc.get("nodes"))
@@ -306,7 +411,7 @@ int rth_geometry_import_glb(const char *path, rth_geometry **out) {
     J doc = jp.value();
     if (!jp.ok || doc.kind != J::Obj) { set_error("GLTF import error: bad JSON"); return RT_E_INVALID; }
     auto geo = std::make_unique<rth_geometry>();
-    Importer imp{doc, bin, bin_len, geo->mesh, {}, {}};
+    Importer imp{doc, bin, bin_len, geo->mesh, *geo, {}, {}};
     if (!imp.run()) { set_error("GLTF import error: %s", imp.err.c_str()); return RT_E_INVALID; }
     *out = geo.release();
     return RT_OK;
@@ -319,6 +424,35 @@ void rth_geometry_view(const rth_geometry *g, const rtg_vertex **verts, uint32_t
     *verts = g->mesh.verts.data();     *n_verts = (uint32_t)g->mesh.verts.size();
     *indices = g->mesh.indices.data(); *n_indices = (uint32_t)g->mesh.indices.size();
     *nodes = g->mesh.nodes.data();     *n_nodes = (uint32_t)g->mesh.nodes.size();
+}
+
+void rth_geometry_pbr_materials(const rth_geometry *g, const rth_pbr_material **materials, uint32_t *n_materials) {
+    *materials = g->pbr_materials.data(); *n_materials = (uint32_t)g->pbr_materials.size();
+}
+
+void rth_geometry_vertex_attrs(const rth_geometry *g, const rth_vertex_attrs **attrs, uint32_t *n_verts) {
+    *attrs = g->vertex_attrs.data(); *n_verts = (uint32_t)g->vertex_attrs.size();
+}
+
+int32_t rth_geometry_material_index(const rth_geometry *g, const char *name) {
+    if (!g || !name) return -1;
+    for (size_t k = 0; k < g->pbr_names.size(); ++k) if (g->pbr_names[k] == name) return (int32_t)k;
+    return -1;
+}
+
+int rth_geometry_pbr_images(const rth_geometry *g, int kind, uint32_t *width, uint32_t *height, uint32_t *n_layers,
+                            const uint8_t *const **rgba_layers, const uint32_t **layer_sizes) {
+    if (!g || kind < 0 || kind > 2 || !width || !height || !n_layers || !rgba_layers) { set_error("null argument or kind outside 0..2"); return RT_E_INVALID; }
+    const int size_kind = kind == 2 ? 1 : kind;     // sic: pbr_normal_images takes its size from the metallic-roughness list (geometry_import.rs:135)
+    if (g->layer_ptrs[kind].empty() || g->layer_ptrs[size_kind].empty()) { set_error("the file has no materials"); return RT_E_INVALID; }   // images[..[0]] panics
+    for (const uint8_t *p : g->layer_ptrs[kind])
+        if (!p) { set_error("an image of this list is not embedded in the file or could not be decoded"); return RT_E_UNSUPPORTED_PRIMITIVE; }
+    if (!g->layer_ptrs[size_kind][0]) { set_error("the first metallic-roughness image could not be decoded"); return RT_E_UNSUPPORTED_PRIMITIVE; }
+    *width = g->layer_sizes[size_kind][0]; *height = g->layer_sizes[size_kind][1];
+    *n_layers = (uint32_t)g->layer_ptrs[kind].size();
+    *rgba_layers = g->layer_ptrs[kind].data();
+    if (layer_sizes) *layer_sizes = g->layer_sizes[kind].data();
+    return RT_OK;
 }
 
 }  // extern "C"

@@ -70,6 +70,16 @@ struct Mesh {
 
 struct rth_geometry {
     rth::Mesh mesh;  // imported (object-space) vertices
+    // the PBR side (geometry_import.rs:172-304): material table, per-vertex extras, the three image lists
+    std::vector<rth_pbr_material> pbr_materials;
+    std::vector<std::string> pbr_names;              // gltf_mat_2_pbr_mat_mapping, in table order
+    std::vector<rth_vertex_attrs> vertex_attrs;
+    struct Image { uint32_t width = 0, height = 0; uint8_t *rgba = nullptr; };
+    std::vector<Image> images;                       // every image of the document, decoded to RGBA8 (null if it could not be)
+    std::vector<uint32_t> image_list[3];             // per kind: the distinct source image indices, ascending
+    std::vector<const uint8_t *> layer_ptrs[3];
+    std::vector<uint32_t> layer_sizes[3];
+    ~rth_geometry() { for (Image &im : images) if (im.rgba) rth_image_free(im.rgba); }
 };
 
 struct rth_scene {

@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
 // iteration finds an empty pool.  One wave per block: a block's waves would only wait for each other.
 template <bool STATS, int EXT>
 __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ q, const WfCounters *ctr, uint32_t it, uint32_t tail_max,
-                                                     uint32_t lds_depth, StackEntry *ovf, float4 *__restrict__ samples, uint32_t *status,
+                                                     uint32_t set_lanes, uint32_t lds_depth, StackEntry *ovf, float4 *__restrict__ samples, uint32_t *status,
                                                      unsigned long long *stats, uint32_t *pixel_rays) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wpb = blockDim.x >> 6;
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
     if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 0u;   // what the next generate would report
     // The live paths sit unevenly in the shards (a shard holds neighbouring tiles: sky dies at once, a glass sphere lives to the
     // depth limit), so the sets of 64 paths are numbered through all shards and dealt to the waves of the launch round-robin.
-    uint32_t sets_incl = (my_count + 63u) >> 6;          // inclusive prefix sum of the shards' set counts
+    uint32_t sets_incl = (my_count + set_lanes - 1u) / set_lanes;          // inclusive prefix sum of the shards' set counts
     for (uint32_t o = 1; o < 64u; o <<= 1) {
         const uint32_t up = (uint32_t)__shfl_up((int)sets_incl, o, 64);
         if (lane >= o) sets_incl += up;
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
     for (uint32_t set = gw; set < n_sets; set += n_gw) {
         const uint32_t shard = (uint32_t)__popcll(__ballot(sets_incl <= set));          // first shard whose prefix exceeds `set`
         const uint32_t first_set = shard ? (uint32_t)__shfl((int)sets_incl, (int)shard - 1, 64) : 0u;
-        const uint32_t n = (uint32_t)__shfl((int)my_count, (int)shard, 64), off = (set - first_set) * 64u;
+        const uint32_t n = (uint32_t)__shfl((int)my_count, (int)shard, 64), off = (set - first_set) * set_lanes;
         const uint32_t i = shard * w.cap + off + lane;
         bool alive = false, walk = false;
         WfPath p;
@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
         Trav tv;
         tv.ref = RT_BVH_EMPTY; tv.sp = 0; tv.best.t = 0.0f; tv.best.id = -1; tv.best.slot = 0; tv.floor_id = -1;
         tv.inv = p.ps.ray.o; tv.oi = p.ps.ray.o;
-        if (off + lane < n) {
+        if (lane < set_lanes && off + lane < n) {
             const float4 d = q.ray_d[i];
             const uint32_t flags = __float_as_uint(d.w);
             if (flags & WF_ALIVE) {

@@ -140,6 +140,36 @@ class Geometry:
         nodes = np.ctypeslib.as_array(C.cast(nd, _ffi.c_u32_p), (nn.value, 2)).copy()
         return verts, idx, nodes
 
+    def pbr_materials(self):
+        """ImportedGeometry::pbr_materials (geometry_import.rs:96-98): structured array, one PbrMaterial per glTF material."""
+        m, n = C.POINTER(_ffi.rth_pbr_material)(), C.c_uint32()
+        _ffi.host_lib().rth_geometry_pbr_materials(self._h, C.byref(m), C.byref(n))
+        dt = np.dtype([("base_color_factor", "<f4", 3), ("metallic_factor", "<f4"), ("roughness_factor", "<f4"),
+                       ("base_color_texarray_id", "<u4"), ("metallic_rough_texarray_id", "<u4"), ("normal_texarray_id", "<u4")])
+        if n.value == 0:
+            return np.zeros(0, dt)
+        return np.frombuffer(C.string_at(m, n.value * C.sizeof(_ffi.rth_pbr_material)), dtype=dt).copy()
+
+    def vertex_attrs(self):
+        """colour, tangent and pbr_buf_id of every vertex (geometry_import.rs:47-68), parallel to view()'s vertices."""
+        a, n = C.POINTER(_ffi.rth_vertex_attrs)(), C.c_uint32()
+        _ffi.host_lib().rth_geometry_vertex_attrs(self._h, C.byref(a), C.byref(n))
+        dt = np.dtype([("color", "<f4", 4), ("tangent", "<f4", 4), ("pbr_buf_id", "<u4")])
+        if n.value == 0:
+            return np.zeros(0, dt)
+        return np.frombuffer(C.string_at(a, n.value * C.sizeof(_ffi.rth_vertex_attrs)), dtype=dt).copy()
+
+    def material_index(self, name):
+        return int(_ffi.host_lib().rth_geometry_material_index(self._h, name.encode()))
+
+    def pbr_images(self, kind):
+        """pbr_base_color_images / pbr_metallic_roughness_images / pbr_normal_images (kind 0 / 1 / 2): (width, height, [RGBA8 layers])."""
+        w, h, n = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        layers, sizes = C.POINTER(_ffi.c_u8_p)(), _ffi.c_u32_p()
+        _check(_ffi.host_lib().rth_geometry_pbr_images(self._h, kind, C.byref(w), C.byref(h), C.byref(n), C.byref(layers), C.byref(sizes)))
+        out = [np.ctypeslib.as_array(layers[i], (sizes[2 * i + 1], sizes[2 * i], 4)).copy() for i in range(n.value)]
+        return w.value, h.value, out
+
     def __del__(self):
         if getattr(self, "_h", None):
             _ffi.host_lib().rth_geometry_free(self._h)

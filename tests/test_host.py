@@ -393,6 +393,116 @@ def test_glb_import_counts_and_quaternion_quirk(rt):
         rt.host.Geometry("/nonexistent.glb")
 
 
+def glb_json_and_bin(path):
+    d = open(path, "rb").read()
+    jlen = struct.unpack("<I", d[12:16])[0]
+    return json.loads(d[20:20 + jlen]), d[20 + ((jlen + 3) & ~3) + 8:]
+
+
+def test_glb_pbr_side_of_the_teapot(rt):
+    # geometry_import.rs:172-304 + 385-425 against the file's own JSON, read here with the json module
+    from PIL import Image
+    import io
+    path = os.path.join(rt.host.DATA_DIR, "models/teapot/teapot.glb")
+    j, blob = glb_json_and_bin(path)
+    geo = rt.host.Geometry(path)
+    mats = geo.pbr_materials()
+    assert len(mats) == len(j["materials"]) == 1
+    m = mats[0]
+    assert m["base_color_factor"].tolist() == [1.0, 1.0, 1.0] and m["metallic_factor"] == 0.0 and m["roughness_factor"] == 1.0   # glTF defaults
+    assert (m["base_color_texarray_id"], m["metallic_rough_texarray_id"], m["normal_texarray_id"]) == (0, 0, 0)                   # one layer per list
+    assert geo.material_index("utahTeapot") == 0 and geo.material_index("nope") == -1
+    attrs = geo.vertex_attrs()
+    verts, _, _ = geo.view()
+    assert len(attrs) == len(verts) and np.all(attrs["pbr_buf_id"] == 0)
+    assert np.all(attrs["color"] == np.array([0, 0, 0, 1], np.float32))           # no COLOR_0 in the file: GeometryVertex::default
+    want = []
+    for mesh in j["meshes"]:
+        for prim in mesh["primitives"]:
+            acc = j["accessors"][prim["attributes"]["TANGENT"]]
+            bv = j["bufferViews"][acc["bufferView"]]
+            assert acc["componentType"] == 5126 and acc["type"] == "VEC4" and "byteStride" not in bv
+            want.append(np.frombuffer(blob, np.float32, acc["count"] * 4, bv.get("byteOffset", 0) + acc.get("byteOffset", 0)).reshape(-1, 4))
+    assert np.array_equal(attrs["tangent"], np.concatenate(want))                  # copied verbatim (not transformed, :415-419)
+    # the three lists: base colour = image of texture 1, metallic-roughness = texture 2, normal = texture 0
+    mat = j["materials"][0]
+    src = lambda t: j["textures"][t["index"]]["source"]
+    for kind, tex in enumerate((mat["pbrMetallicRoughness"]["baseColorTexture"], mat["pbrMetallicRoughness"]["metallicRoughnessTexture"], mat["normalTexture"])):
+        w, h, layers = geo.pbr_images(kind)
+        bv = j["bufferViews"][j["images"][src(tex)]["bufferView"]]
+        png = Image.open(io.BytesIO(blob[bv.get("byteOffset", 0):bv.get("byteOffset", 0) + bv["byteLength"]])).convert("RGBA")
+        assert len(layers) == 1 and np.array_equal(layers[0], np.asarray(png))
+        size_of = mat["pbrMetallicRoughness"]["metallicRoughnessTexture"] if kind == 2 else tex     # sic, geometry_import.rs:135
+        bv2 = j["bufferViews"][j["images"][src(size_of)]["bufferView"]]
+        assert (w, h) == Image.open(io.BytesIO(blob[bv2.get("byteOffset", 0):bv2.get("byteOffset", 0) + bv2["byteLength"]])).size
+
+
+def make_glb(doc, blob):
+    js = json.dumps(doc).encode()
+    js += b" " * (-len(js) % 4)
+    blob += b"\0" * (-len(blob) % 4)
+    body = struct.pack("<II", len(js), 0x4e4f534a) + js + struct.pack("<II", len(blob), 0x004e4942) + blob
+    return struct.pack("<III", 0x46546c67, 2, 12 + len(body)) + body
+
+
+def test_glb_pbr_texture_layers_follow_sort_and_dedup(rt, tmp_path):
+    # three materials that share images out of order: a layer id is the image's rank among the DISTINCT images of its kind
+    # (geometry_import.rs:225-297); primitives find their material by name (:363-375); COLOR_0 as u8 RGB -> rgba f32 (:421-425)
+    from PIL import Image
+    import io
+    blob, views, images = b"", [], []
+    def add(data, **kw):
+        nonlocal blob
+        blob += b"\0" * (-len(blob) % 4)
+        views.append(dict(buffer=0, byteOffset=len(blob), byteLength=len(data), **kw))
+        blob += data
+        return len(views) - 1
+    pixels = []
+    for k in range(5):                                   # five 2x1 PNGs, RGB and RGBA mixed
+        im = Image.new("RGBA" if k % 2 else "RGB", (2 + k, 1), (10 * k, 20, 30) + ((40,) if k % 2 else ()))
+        b = io.BytesIO(); im.save(b, "PNG")
+        images.append(dict(bufferView=add(b.getvalue()), mimeType="image/png"))
+        pixels.append(np.asarray(im.convert("RGBA")))
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    col = np.array([[255, 0, 51], [0, 255, 0], [0, 0, 255]], np.uint8)
+    acc = [dict(bufferView=add(pos.tobytes()), componentType=5126, count=3, type="VEC3"),
+           dict(bufferView=add(np.array([0, 1, 2], np.uint16).tobytes()), componentType=5123, count=3, type="SCALAR"),
+           dict(bufferView=add(np.pad(col, ((0, 0), (0, 1))).tobytes(), byteStride=4), componentType=5121, count=3, type="VEC3", normalized=True)]
+    tex = [dict(source=k) for k in range(5)]
+    mk = lambda name, base, mr, nrm, **pbr: dict(name=name, normalTexture=dict(index=nrm),
+                                                 pbrMetallicRoughness=dict(baseColorTexture=dict(index=base), metallicRoughnessTexture=dict(index=mr), **pbr))
+    mats = [mk("c", 4, 3, 0, baseColorFactor=[0.5, 0.25, 0.125, 0.75], roughnessFactor=0.5), mk("a", 1, 3, 2), mk("b", 4, 0, 2, metallicFactor=0.25)]
+    prim = lambda m: dict(attributes=dict(POSITION=0, COLOR_0=2), indices=1, material=m)
+    doc = dict(asset=dict(version="2.0"), scenes=[dict(nodes=[0])], nodes=[dict(mesh=0)], meshes=[dict(primitives=[prim(2), prim(0), prim(1)])],
+               materials=mats, textures=tex, images=images, accessors=acc, bufferViews=views, buffers=[dict(byteLength=len(blob))])
+    path = tmp_path / "three_materials.glb"
+    path.write_bytes(make_glb(doc, blob))
+    geo = rt.host.Geometry(str(path))
+    m = geo.pbr_materials()
+    # base colour images {4, 1} -> layers 1:0, 4:1; metallic-roughness {3, 0} -> 0:0, 3:1; normal {0, 2} -> 0:0, 2:1
+    assert m["base_color_texarray_id"].tolist() == [1, 0, 1]
+    assert m["metallic_rough_texarray_id"].tolist() == [1, 1, 0]
+    assert m["normal_texarray_id"].tolist() == [0, 1, 1]
+    assert m["base_color_factor"].tolist() == [[0.5, 0.25, 0.125], [1, 1, 1], [1, 1, 1]]
+    assert m["metallic_factor"].tolist() == [1.0, 1.0, 0.25] and m["roughness_factor"].tolist() == [0.5, 1.0, 1.0]
+    assert [geo.material_index(n) for n in "abc"] == [1, 2, 0]
+    a = geo.vertex_attrs()
+    assert a["pbr_buf_id"].tolist() == [2] * 3 + [0] * 3 + [1] * 3
+    assert np.array_equal(a["color"][:3], np.concatenate([col.astype(np.float32) / np.float32(255), np.ones((3, 1), np.float32)], axis=1))
+    assert np.all(a["tangent"] == 0)
+    w, h, layers = geo.pbr_images(0)
+    assert (w, h) == (3, 1) and len(layers) == 2 and np.array_equal(layers[0], pixels[1]) and np.array_equal(layers[1], pixels[4])
+    w, h, layers = geo.pbr_images(2)
+    assert (w, h) == (2, 1) and np.array_equal(layers[1], pixels[2])     # sic: the size is the first metallic-roughness layer's (image 0)
+    # the reference's panics are errors here: a material without a name, without one of the three textures, a duplicate name
+    for bad in (lambda d: d["materials"][1].pop("name"), lambda d: d["materials"][0].pop("normalTexture"),
+                lambda d: d["materials"][2].update(name="a")):
+        d2 = json.loads(json.dumps(doc)); bad(d2)
+        path.write_bytes(make_glb(d2, blob))
+        with pytest.raises(rt.RtError):
+            rt.host.Geometry(str(path))
+
+
 def test_mesh_scene_teapot_stands_on_the_floor(rt):
     assets = rt.host.Assets(need=("uvgrid01", "uvgrid09", "teapot"))
     s = rt.host.Scene.build("MeshTest", assets=assets)
