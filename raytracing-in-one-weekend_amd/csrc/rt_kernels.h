@@ -1299,6 +1299,11 @@ struct Path {
 
 // Everything ray_color does after world.hit() returned `best` (camera.rs:264-308).  Returns true
 // while the path continues (ps.ray is then the scattered ray and ps.depth is one less).
+// A path that ends on black (depth used up, camera.rs:260; an absorbed ray or the back of an emitter: `emitted` is black).  The
+// recursion multiplies that black by every attenuation factor on its way up, so a factor that is NaN or infinite (a light's
+// pdf_value from inside the light, sphere.rs:95-99) makes the sample NaN, not black: the forward form has to say so as well.
+RT_DEV void end_on_black(Path &ps) { ps.radiance = ps.radiance + ps.throughput * v3(0.0f, 0.0f, 0.0f); }
+
 template <bool STATS, int EXT = EXT_ALL>
 RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background, rts::Rng &rng, Counters &cnt) {
     if (best.id < 0) {
@@ -1343,6 +1348,8 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
         if (rec.front_face) {
             V3 e = material_texture<STATS, EXT>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
             ps.radiance = ps.radiance + ps.throughput * e;
+        } else {
+            end_on_black(ps);
         }
         RG_END(RG_EMIT);
         return false;
@@ -1352,7 +1359,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
         V3 reflected = reflect_unit_vector(r.d, normalize(rec.normal));
         V3 scattered = reflected + mb.y * random_in_unit_sphere(rng);
         RG_END(RG_METAL);
-        if (!(dot(scattered, rec.normal) > 0.0f)) return false;  // None -> emitted = 0
+        if (!(dot(scattered, rec.normal) > 0.0f)) { end_on_black(ps); return false; }  // None -> emitted = 0
         ps.throughput = ps.throughput * v3(ma.z, ma.w, mb.x);
         ps.ray = Ray{rec.p, scattered, r.time};
         break;

@@ -451,7 +451,10 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
         const bool cont = shade_hit<STATS, EXT>(sc, p.ps, tv.best, background, p.rng, cnt);
         RG_END(RG_SHADE_ALL);
         if (cont && p.ps.depth > 0) survive = true;
-        else samples[p.item] = make_float4(p.ps.radiance.x, p.ps.radiance.y, p.ps.radiance.z, 0.0f);
+        else {
+            if (cont) end_on_black(p.ps);      // the next call would return black at depth 0 (camera.rs:260)
+            samples[p.item] = make_float4(p.ps.radiance.x, p.ps.radiance.y, p.ps.radiance.z, 0.0f);
+        }
     }
     phase_count<STATS>(cnt, PH_BEGIN, survive);
     if (survive) {
@@ -567,8 +570,10 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
             RG_BEGIN(RG_SHADE_ALL);
             if (alive) {
                 finish_trace<STATS, EXT>(sc, p.ps.ray, T_MIN, INFINITY, tv, cnt);
-                survive = shade_hit<STATS, EXT>(sc, p.ps, tv.best, background, p.rng, cnt) && p.ps.depth > 0;
+                const bool cont = shade_hit<STATS, EXT>(sc, p.ps, tv.best, background, p.rng, cnt);
+                survive = cont && p.ps.depth > 0;
                 if (!survive) {
+                    if (cont) end_on_black(p.ps);
                     samples[p.item] = make_float4(p.ps.radiance.x, p.ps.radiance.y, p.ps.radiance.z, 0.0f);
                     alive = false;
                 }

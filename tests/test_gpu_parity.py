@@ -307,3 +307,62 @@ def test_paths_deeper_than_255_bounces(rt, gpu):
     g_img, c_img, stats = compare_images(rt, gpu, O.OracleScene(s), params, camera, sampler)
     assert stats["rays"] > 200 * stats["paths"], "most paths should reach the depth limit"
     assert stats["node_visits"] > 0 and stats["box_tests"] >= stats["node_visits"]
+
+
+@pytest.mark.gpu
+def test_wrapped_lights_forward_their_pdf_untransformed(rt, gpu):
+    """`lights` may hold wrapped objects: Translate / RotateY / Transform forward pdf_value and random to the object they wrap
+    WITHOUT transforming (transform.rs:48-54, 146-152, 206-212), so the direction that is sampled aims at where the inner object
+    would be; FlipFace and Block keep the trait defaults (pdf 0, random = unit_x, hittable.rs:47-53).  All of it against the
+    oracle, with per-pixel ray counts equal."""
+    def build(with_defaults):
+        s = rt.host.Scene()
+        grey, red = s.lambertian(s.solid(0.7, 0.7, 0.7)), s.lambertian(s.solid(0.7, 0.2, 0.2))
+        lamp, dark = s.diffuse_light(s.solid(9, 9, 9)), s.diffuse_light(s.solid(0, 0, 0))
+        world = [s.xz_rect(-20, 20, -20, 20, 0, grey), s.sphere((-2, 1, 0), 1, red), s.block((1, 0, -1), (2.5, 1.5, 0.5), grey),
+                 s.flip_face(s.translate(s.xz_rect(-1, 1, -1, 1, 5, lamp), (1.5, 0, 0.5))),          # the emitters, where the wrappers put them
+                 s.rotate_y(s.sphere((4, 3, 0), 0.5, lamp), 40.0)]
+        m = np.eye(4, dtype=np.float32); m[:3, 3] = (0, 1, -3); m[0, 0] = 2
+        lights = [s.translate(s.xz_rect(-1, 1, -1, 1, 5, dark), (1.5, 0, 0.5)),       # sampled as the bare rectangle at x, z in [-1, 1]
+                  s.rotate_y(s.sphere((4, 3, 0), 0.5, dark), 40.0),                   # ... as the sphere before the rotation
+                  s.transform(s.yz_rect(0, 1, 0, 1, 2, dark), m),
+                  s.translate(s.rotate_y(s.xy_rect(-1, 1, 2, 3, -4, dark), 15.0), (0, 0, 1))]   # two wrappers deep
+        if with_defaults:
+            lights += [s.flip_face(s.xz_rect(-1, 1, -1, 1, 5, dark)),                 # trait defaults: pdf 0, random = (1, 0, 0)
+                       s.block((0, 0, 0), (1, 1, 1), dark)]
+        s.set_roots(s.hittable_list(world), s.hittable_list(lights))
+        return s
+    params = rt.host.RaytracerConfig.load().scene_params("CornellBox").replace(
+        image_width=96, aspect_ratio=1.5, samples_per_pixel=16, look_from=(0.0, 3.0, 11.0), look_at=(0.5, 1.5, 0.0),
+        vertical_fov=40.0, background=(0.02, 0.02, 0.03))
+    camera, sampler = params.camera(), rt.host.MultiJitteredSampler(16)
+    gpu.upload_sampler(sampler)
+    s = build(False)
+    flat = s.flatten()
+    assert flat.desc.n_lights == 4
+    gpu.upload_scene(flat)
+    oracle = O.OracleScene(s)
+    g_img, c_img, stats = compare_images(rt, gpu, oracle, params, camera, sampler)
+    assert stats["light_pdf_evals"] > 0 and np.isfinite(g_img[..., :3]).all() and g_img[..., :3].max() > 1.0
+    # forwarding means: the list's pdf is that of the bare inner objects
+    bare = rt.host.Scene()
+    d2 = bare.diffuse_light(bare.solid(0, 0, 0))
+    bare.set_roots(bare.hittable_list([bare.sphere((0, 0, 0), 1, d2)]),
+                   bare.hittable_list([bare.xz_rect(-1, 1, -1, 1, 5, d2), bare.sphere((4, 3, 0), 0.5, d2), bare.yz_rect(0, 1, 0, 1, 2, d2),
+                                       bare.xy_rect(-1, 1, 2, 3, -4, d2)]))
+    o_bare = O.OracleScene(bare)
+    rng = np.random.default_rng(5)
+    o = rng.uniform(-3, 3, (256, 3)).astype(np.float32); o[:, 1] = np.abs(o[:, 1])
+    v = rng.normal(size=(256, 3)).astype(np.float32); v[:, 1] = np.abs(v[:, 1])
+    vals = [oracle.lights_pdf_value(o[k], v[k]) for k in range(256)]
+    assert vals == [o_bare.lights_pdf_value(o[k], v[k]) for k in range(256)] and max(vals) > 0
+    # With the two trait-default entries many samples are NaN in the reference's arithmetic (random = unit_x lies in the floor's
+    # plane and runs into +-inf / NaN distances and pdfs; a path that then ends on black is 0 * NaN on the way up the recursion).
+    # The kernels' forward form must give NaN in exactly those pixels and the same numbers elsewhere (compare_images).
+    s = build(True)
+    flat = s.flatten()
+    assert flat.desc.n_lights == 6
+    gpu.upload_scene(flat)
+    g_img, c_img, _ = compare_images(rt, gpu, O.OracleScene(s), params, camera, sampler)
+    nan = np.isnan(g_img[..., :3]).any(-1)
+    assert np.array_equal(nan, np.isnan(c_img[..., :3]).any(-1)) and 0 < nan.mean() < 0.9
