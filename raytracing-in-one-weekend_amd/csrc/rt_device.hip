@@ -173,6 +173,20 @@ void magic_div(uint32_t d, uint32_t *m, uint32_t *k) {
     *m = (uint32_t)(((1ull << *k) / d) + 1);
 }
 
+// Hand-out order of a pipeline's tiles (rt_wavefront.h, wf_generate_kernel): a stride near the golden section of their number,
+// coprime to it, with (n - 1) * stride < 2^32.  RT_WF_TILE_STRIDE=1 restores raster order (A/B).
+uint32_t tile_stride_for(uint32_t n) {
+    if (n < 4u) return 1u;
+    const size_t forced = env_size("RT_WF_TILE_STRIDE", 0, 0, 0xffffffffu);
+    uint64_t s = forced ? forced % n : (uint64_t)((double)n * 0.6180339887498949);
+    const uint64_t cap = 0xffffffffull / n;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+    while (s > 1 && gcd(s, n) != 1) --s;
+    return (uint32_t)s;
+}
+
 // The streaming pipeline of rt_wavefront.h for one rt_render call.  Samples are rendered in batches
 // that fit the sample buffer.  A batch's items are split over RT_WF_PIPES independent pipelines (own
 // pool, counters and HIP stream): traverse is bound by memory latency and LDS, shade by registers,
@@ -333,7 +347,11 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             magic_div(spp_batch, &w.spp_m, &w.spp_k);
             // pipe q renders the tiles t with t % n_pipes == q: whole tiles, so an item's index is the same with any number of pipes
             w.pipe = (uint32_t)q; w.n_pipes = (uint32_t)n_pipes;
-            w.n_items = ((n_tiles - (uint32_t)q + (uint32_t)n_pipes - 1u) / (uint32_t)n_pipes) * spp_batch * 64u;
+            w.tiles_pipe = (n_tiles - (uint32_t)q + (uint32_t)n_pipes - 1u) / (uint32_t)n_pipes;
+            w.tile_stride = tile_stride_for(w.tiles_pipe);
+            w.tp_m = 0; w.tp_k = 0;
+            if (env_size("RT_WF_SAMPLE_MAJOR", 1, 0, 1)) magic_div(w.tiles_pipe, &w.tp_m, &w.tp_k);
+            w.n_items = w.tiles_pipe * spp_batch * 64u;
             const size_t items_up = ((size_t)w.n_items + shard_q - 1) / shard_q * shard_q;
             w.pool = (uint32_t)(items_up < ctx->wf_pool_entries ? items_up : ctx->wf_pool_entries);
             if (w.pool > pool_want) w.pool = (uint32_t)pool_want;

@@ -69,6 +69,8 @@ struct WfArgs {
     uint32_t sample0;     // absolute index of the batch's first sample
     uint32_t tiles_x, n_tiles;   // 8x8 pixel tiles over the window
     uint32_t spp_m, spp_k, tx_m, tx_k;   // n / spp_batch and n / tiles_x as (n * m) >> k, exact for n < 2^26
+    uint32_t tiles_pipe, tile_stride;    // this pipeline's l-th tile in hand-out order is its tile (l * tile_stride) % tiles_pipe (stride 1: in order)
+    uint32_t tp_m, tp_k;                 // n / tiles_pipe as (n * m) >> k; tp_k == 0: hand out tile by tile (all samples of a tile in a row)
 };
 
 // floor(n / d) for n < 2^26 with (m, k) from the host's magic_div(): k = 26 + ceil(log2 d), m = floor(2^k / d) + 1.
@@ -192,11 +194,19 @@ __global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScen
     const uint32_t off = off0 + threadIdx.x;
     const bool mine = off >= n_surv && off < n_surv + n_new;
     Counters cnt{};
-    // the pipeline's li-th item = sample k of its lt-th tile; items are numbered over the whole batch (tile-major), as the
-    // sample buffer and the fold index them
+    // li = the item's place in the pipeline's hand-out order; g = its index over the whole batch (tile-major), as the sample
+    // buffer and the fold use it
     const uint32_t li = item_head + room_before + (off - n_surv), lg = li >> 6;
-    const uint32_t lt = div_magic(lg, w.spp_m, w.spp_k), lk = lg - lt * w.spp_batch;
-    const uint32_t g = (((lt * w.n_pipes + w.pipe) * w.spp_batch + lk) << 6) | (li & 63u), e = j;
+    // The pipeline's li-th item: sample by sample (group lg = sample lk of the lt-th tile in hand-out order, all tiles at one
+    // sample before the next sample), so neighbouring groups — which end up in the same shard — are different tiles.
+    uint32_t lt, lk;
+    if (w.tp_k) { lk = div_magic(lg, w.tp_m, w.tp_k); lt = lg - lk * w.tiles_pipe; }
+    else { lt = div_magic(lg, w.spp_m, w.spp_k); lk = lg - lt * w.spp_batch; }
+    // Tiles are handed out along a stride that is coprime to their number (a golden-section step through the frame), not in
+    // raster order: a shard's stretch of the item sequence then holds tiles from all over the frame, so every shard — and every
+    // traverse block, which works on one shard — carries the same mix of cheap (sky) and expensive (glass, crowded) pixels.
+    const uint32_t pt = (lt * w.tile_stride) % w.tiles_pipe;      // (the product stays below 2^32, rt_device.hip)
+    const uint32_t g = (((pt * w.n_pipes + w.pipe) * w.spp_batch + lk) << 6) | (li & 63u), e = j;
     WfPath p;
     int x, y;
     const bool inside = mine && item_pixel(w, g, &x, &y, &p.sample);
