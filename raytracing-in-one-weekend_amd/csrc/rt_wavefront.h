@@ -556,22 +556,32 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
         }
         while (__ballot(alive) != 0ull) {
             RG_BEGIN(RG_TRAV_ALL);
-            for (;;) {      // the walk, "while-while" as in the traverse kernel
-                const bool on_node = alive && walk && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY;
-                phase_count<STATS>(cnt, PH_NODE, on_node);
-                RG_BEGIN(RG_NODE);
-                if (on_node) trav_node_step<STATS>(sc, T_MIN, tv, stack, cnt);
-                RG_END(RG_NODE);
-                const bool at_leaf = alive && walk && tv.ref < 0;
-                const unsigned long long m_leaf = __ballot(at_leaf);
-                const unsigned long long m_node = __ballot(alive && walk && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
-                if (m_leaf != 0ull && (__popcll(m_leaf) >= RT_LEAF_MIN || m_node == 0ull)) {
-                    phase_count<STATS>(cnt, PH_LEAF, at_leaf);
-                    RG_BEGIN(RG_LEAF);
-                    if (at_leaf) trav_leaf_step<STATS, EXT & (EXT_XFORM | EXT_TRI)>(sc, p.ps.ray, T_MIN, tv, stack, cnt);
-                    RG_END(RG_LEAF);
-                } else if (m_node == 0ull) {
-                    break;
+            {      // the walk, as wf_traverse_kernel does it without the refill: leaves put aside, RT_WF_NODE_STEPS node steps per turn
+                const bool walking = alive && walk;
+                int32_t pend = RT_BVH_EMPTY;
+                for (;;) {
+#pragma unroll
+                    for (int k = 0; k < RT_WF_NODE_STEPS; ++k) {
+                        if (walking && tv.ref < 0 && pend == RT_BVH_EMPTY) { pend = tv.ref; tv.ref = pop_ref(stack, tv.sp); }
+                        const bool on_node = walking && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY;
+                        phase_count<STATS>(cnt, PH_NODE, on_node);
+                        RG_BEGIN(RG_NODE);
+                        if (on_node) trav_node_step<STATS>(sc, T_MIN, tv, stack, cnt);
+                        RG_END(RG_NODE);
+                    }
+                    if (walking && tv.ref < 0 && pend == RT_BVH_EMPTY) { pend = tv.ref; tv.ref = pop_ref(stack, tv.sp); }
+                    const bool has_leaf = walking && pend != RT_BVH_EMPTY;
+                    const unsigned long long m_leaf = __ballot(has_leaf);
+                    const unsigned long long m_node = __ballot(walking && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY);
+                    if (m_leaf == 0ull && m_node == 0ull) break;
+                    const uint32_t n_leaf = (uint32_t)__popcll(m_leaf);
+                    const uint32_t n_live = (uint32_t)__popcll(__ballot(walking && (tv.ref != RT_BVH_EMPTY || pend != RT_BVH_EMPTY)));
+                    if (m_leaf != 0ull && (n_leaf >= RT_LEAF_MIN || n_leaf * RT_LEAF_FRAC >= n_live || m_node == 0ull)) {
+                        phase_count<STATS>(cnt, PH_LEAF, has_leaf);
+                        RG_BEGIN(RG_LEAF);
+                        if (has_leaf) { trav_leaf_test<STATS, EXT & (EXT_XFORM | EXT_TRI)>(sc, p.ps.ray, T_MIN, tv, pend, cnt); pend = RT_BVH_EMPTY; }
+                        RG_END(RG_LEAF);
+                    }
                 }
             }
             RG_END(RG_TRAV_ALL);
