@@ -64,6 +64,10 @@ def test_reference_image_matches_the_oracle(rt, gpu, book2):
     {"RT_WF_TAIL": 256, "RT_WF_TAIL_BLOCK": 128, "RT_WF_TAIL_EVERY": 3},    # ... a launch of 68 waves
     {"RT_WF_TAIL": 1000000},                       # ... everything that is left once all items are out: its waves take several sets each
     {"RT_WF_TAIL": 3000, "RT_WF_LDS_DEPTH": 3, "RT_WF_PIPES": 1},   # ... with its stack in the overflow area
+    {"RT_WF_TAIL": 20000, "RT_WF_TAIL_SET": 16},   # ... 16 paths per wave
+    {"RT_WF_TILE_STRIDE": 1, "RT_WF_SAMPLE_MAJOR": 0},   # items handed out tile by tile in raster order (default: sample-major along a golden-section stride)
+    {"RT_WF_TILE_STRIDE": 7},
+    {"RT_WF_SAMPLE_MAJOR": 0, "RT_WF_PIPES": 3, "RT_WF_POOL_LOG2": 15},
 ])
 def test_image_is_independent_of_the_pipeline_geometry(gpu, book2, env):
     scene, params, camera, sampler, ref = book2
