@@ -999,8 +999,10 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
     }
     RG_END(RG_B_MEDIA);
     tv.floor_id = -1; tv.sp = 0; tv.ref = RT_BVH_EMPTY;
+    RG_BEGIN(RG_B_RECTS);
     if (!ray_is_finite(r)) {
         closest_hit_exhaustive<STATS, EXT>(sc, r, t_min, t_max, med_t, med_ok, tv.best, cnt);
+        RG_END(RG_B_RECTS);
         return false;
     }
     if (r.d.x == 0.0f || r.d.y == 0.0f || r.d.z == 0.0f)
@@ -1008,10 +1010,12 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
             float t; int32_t id;
             if (slot_hit<STATS, EXT>(sc, sc.rects[i], r, t_min, t_max, &t, &id, cnt) && t != t && id > tv.floor_id) tv.floor_id = id;
         }
+    RG_END(RG_B_RECTS);
     tv.best.t = t_max; tv.best.id = -1; tv.best.slot = 0;
     RG_BEGIN(RG_B_ALWAYS);
     always_scan<STATS, EXT>(sc, r, t_min, t_max, tv.floor_id, tv.best, cnt);
     RG_END(RG_B_ALWAYS);
+    RG_BEGIN(RG_B_REST);
     if (sc.n_moving && !(r.time >= 0.0f && r.time <= 1.0f))
         for (uint32_t i = 0; i < sc.n_moving; ++i) {
             float t; int32_t id;
@@ -1021,10 +1025,11 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
 #pragma unroll
     for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m)
         if ((EXT & EXT_MEDIA) && med_ok[m] && f2i(sc.media[2 * m + 1].z) > tv.floor_id) consider(tv.best, med_t[m], f2i(sc.media[2 * m + 1].z), -(int32_t)(m + 1));
-    if (sc.root_ref == RT_BVH_EMPTY) return false;
+    if (sc.root_ref == RT_BVH_EMPTY) { RG_END(RG_B_REST); return false; }
     tv.inv = box_inv(r.d);
     tv.oi = r.o * tv.inv;
     tv.ref = sc.root_ref;
+    RG_END(RG_B_REST);
     return true;
 }
 

@@ -456,7 +456,9 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
         p.rng.inc = (((((uint64_t)p.pixel << 24) ^ (uint64_t)p.sample)) << 1u) | 1u;   // rts::path_rng's stream
         tv.best.t = h.x; tv.best.id = f2i(h.y); tv.best.slot = f2i(h.z); tv.floor_id = f2i(h.w);
         RG_END(RG_LOAD);
+        RG_BEGIN(RG_FINISH);
         finish_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, tv, cnt);
+        RG_END(RG_FINISH);
         RG_BEGIN(RG_SHADE_ALL);
         const bool cont = shade_hit<STATS, EXT>(sc, p.ps, tv.best, background, p.rng, cnt);
         RG_END(RG_SHADE_ALL);

@@ -38,7 +38,8 @@ def line(k, indent=""): print("%s%-10s %6.2f%%  %8.1f wave-cycles/ray" % (indent
 print("-- shade kernel"); [line(k) for k in top_s]
 print("   inside shade_hit:"); [line(k, "   ") for k in ("RECORD", "EMIT", "METAL", "DIEL", "ISO", "LAMBERT")]
 print("      inside lambertian:"); [line(k, "      ") for k in ("TEXTURE", "L_LIGHTS", "L_COSINE", "L_PDF")]
-print("   inside begin_trace:"); [line(k, "   ") for k in ("B_MEDIA", "B_ALWAYS")]
+print("   inside begin_trace:"); [line(k, "   ") for k in ("B_MEDIA", "B_RECTS", "B_ALWAYS", "B_REST")]
+line("FINISH")
 print("-- traverse kernel"); [line(k) for k in top_t]
 print("-- generate: camera"); line("CAMERA")
 
