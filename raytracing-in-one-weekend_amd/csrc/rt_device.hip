@@ -289,16 +289,19 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     const bool debug = getenv("RT_DEBUG") != nullptr;
     unsigned long long *d_stats = (STATS || kTimers) ? ctx->d_stats : nullptr;
     if (STATS || kTimers) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 128 * sizeof(unsigned long long), stream));
-    // the tail kernel (rt_wavefront.h): finishes the last RT_WF_TAIL paths of a batch in one launch; 0 = never.  Default: on for
-    // scenes without a BVH walk (measured on MI355X, 32768 against 0: C2 at 16 / 64 / 1000 spp +18 / +8 / +1 %), off with one:
-    // there a bounce costs a lone wave as much as an iteration costs the pipeline (C4 at 4 spp +22 %, but C1 at 10 spp, whose last
-    // paths rattle inside glass spheres for 40 bounces, -23 %).
+    // the tail kernel (rt_wavefront.h): once every item is out and at most RT_WF_TAIL paths live, an iteration is RT_WF_TAIL_BOUNCES
+    // bounces of every path in one launch instead of traverse + shade; 0 = never.  Measured on MI355X against 0: C1 at 10 spp
+    // 5.2 -> 3.1 ms, C4 at 4 spp +40 %, C2 at 16 spp +18 %, the long renders +1 %.
     auto *const tail_kernel = K.tail;
     const uint32_t tail_max = (uint32_t)env_size("RT_WF_TAIL", 131072, 0, 1u << 20);
-    const int tail_every = (int)env_size("RT_WF_TAIL_EVERY", 2, 1, 16);   // iterations between two looks
+    const int tail_every = (int)env_size("RT_WF_TAIL_EVERY", 2, 1, 16);   // while the host does not know whether every item is out: every n-th iteration may be a tail iteration
+    const uint32_t tail_bounces = (uint32_t)env_size("RT_WF_TAIL_BOUNCES", 4, 1, 1u << 16);   // bounces of the first tail iteration (then the survivors are compacted)
+    const uint32_t tail_thin = (uint32_t)env_size("RT_WF_TAIL_THIN", 1024, 0, 1u << 16);   // fewer paths per wave while that keeps the waves at or below this number (0: never)
+    const uint32_t tail_bounces2 = (uint32_t)env_size("RT_WF_TAIL_BOUNCES2", 64, 1, 1u << 16); // ... of every later one
     const size_t tail_set_env = env_size("RT_WF_TAIL_SET", 64, 8, 64);
     const uint32_t tail_set = tail_set_env >= 64 ? 64u : tail_set_env >= 32 ? 32u : tail_set_env >= 16 ? 16u : 8u;   // paths per wave
     unsigned tail_waves = tail_max / tail_set + RT_WF_SHARDS;            // one lane per path, one wave per set (a shard's last set may be ragged)
+    if (tail_waves < tail_thin + RT_WF_SHARDS) tail_waves = tail_thin + RT_WF_SHARDS;
     if (tail_waves > trav_blocks * 4u) tail_waves = trav_blocks * 4u;    // its lanes share the pipeline's stack overflow area
     tail_waves = (tail_waves + 3u) / 4u * 4u;
     const size_t tail_blk_env = env_size("RT_WF_TAIL_BLOCK", 256, 64, 256);
@@ -349,6 +352,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             w.pipe = (uint32_t)q; w.n_pipes = (uint32_t)n_pipes;
             w.tiles_pipe = (n_tiles - (uint32_t)q + (uint32_t)n_pipes - 1u) / (uint32_t)n_pipes;
             w.tile_stride = tile_stride_for(w.tiles_pipe);
+            w.tail_max = tail_max;
             w.tp_m = 0; w.tp_k = 0;
             if (env_size("RT_WF_SAMPLE_MAJOR", 1, 0, 1)) magic_div(w.tiles_pipe, &w.tp_m, &w.tp_k);
             w.n_items = w.tiles_pipe * spp_batch * 64u;
@@ -366,21 +370,23 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, w, P.Q[1], P.ctr, P.it,
                                ctx->wf_samples, P.d_status, d_stats, d_rays);
         }
-        auto launch_tail = [&](Pipe &P) {   // on the pool buffer the generate of iteration P.it has just completed
-            hipLaunchKernelGGL(tail_kernel, dim3(tail_waves * 64u / tail_blk), dim3(tail_blk), tail_lds, P.s, ctx->sc, P.w, P.Q[(P.it + 1u) & 1u], P.ctr,
-                               P.it + 1u, tail_max, tail_set, lds_depth, P.ovf, ctx->wf_samples, P.d_status, d_stats, d_rays);
-        };
         auto enqueue_iteration = [&](Pipe &P) {
             if (P.items_out && P.it >= P.it_end) return;   // every path has run out of depth by then: nothing left to enqueue
             const uint32_t it = ++P.it;
             const PathQ &cur = P.Q[it & 1], &nxt = P.Q[(it + 1) & 1];
+            // may this iteration be a tail iteration (the kernels decide from the counters: WfShard::tail_mode)?  Once the host
+            // knows that every item is out: each one; before that every tail_every-th, so that a batch whose status the host has
+            // not seen yet does not wait for it
+            const uint32_t with_tail = tail_max && (P.items_out || (int)(it % (uint32_t)tail_every) == tail_every - 1) ? 1u : 0u;
             if (has_bvh) hipLaunchKernelGGL(trav_kernel, dim3(P.trav_blocks), dim3(256), lds, P.s, ctx->sc, cur, P.ctr, it, P.w.cap,
-                                            lds_depth, P.ovf, d_stats);
+                                            lds_depth, P.ovf, d_stats, with_tail);
             hipLaunchKernelGGL(K.shade, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
-                               ctx->wf_samples, d_stats, d_rays);
+                               ctx->wf_samples, d_stats, d_rays, with_tail);
+            if (with_tail)
+                hipLaunchKernelGGL(tail_kernel, dim3(tail_waves * 64u / tail_blk), dim3(tail_blk), tail_lds, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
+                                   tail_bounces, tail_bounces2, tail_set, tail_thin, lds_depth, P.ovf, ctx->wf_samples, d_stats, d_rays);
             hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, nxt, P.ctr, it,
                                ctx->wf_samples, P.d_status, d_stats, d_rays);
-            if (tail_max && (int)(it % (uint32_t)tail_every) == tail_every - 1) launch_tail(P);
         };
         // groups of 8 iterations while items are handed out; 2 in the tail, where what is enqueued after the pool has drained
         // (the host learns of it a group late) is pure waste
@@ -411,11 +417,12 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                         P.chunks = need < 1u ? 1u : (need < P.w.cap / 256u ? need : P.w.cap / 256u);
                         const unsigned tb = P.chunks * RT_WF_SHARDS;
                         P.trav_blocks = tb < trav_blocks ? tb : trav_blocks;
-                        if (tail_max && hs[0] <= tail_max) {   // what is left fits one tail launch (and only shrinks): that launch ends the batch
-                            launch_tail(P);
-                            HIP_TRY(ctx, hipGetLastError());
-                            P.drained = true; --live;
-                            continue;
+                        if (tail_max && hs[0] <= tail_max) {   // tail mode (the pool only shrinks): every iteration from here takes tail_bounces
+                            // units of depth off every path, so this many more iterations empty the pool whatever the scene
+                            const uint32_t depth = (uint32_t)(a.max_depth > 0 ? a.max_depth : 0);
+                            const uint32_t per_it = tail_bounces < tail_bounces2 ? tail_bounces : tail_bounces2;
+                            const uint32_t end = P.it + (depth + per_it - 1u) / per_it + 1u;
+                            if (end < P.it_end) P.it_end = end;
                         }
                     }
                 }

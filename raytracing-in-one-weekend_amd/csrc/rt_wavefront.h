@@ -51,7 +51,9 @@ struct WfShard {
     uint32_t n_surv;     // entries shade has appended to this shard of the next buffer
     uint32_t cursor;     // traverse's fetch cursor in this shard
     uint32_t item_head;  // (shard 0 only) first item not handed out when this iteration's generate runs
-    uint32_t pad[60];
+    uint32_t tail_mode;  // != 0: every item is out and at most WfArgs::tail_max paths live, this iteration may be run by wf_tail_kernel
+                         // (n = the n-th iteration in a row for which that holds)
+    uint32_t pad[59];
 };
 static_assert(RT_WF_SHARDS == 64u, "generate sums the shard counters with one wave");
 struct WfCounters {      // one per iteration, in a ring; written by the previous iteration's generate
@@ -71,6 +73,7 @@ struct WfArgs {
     uint32_t spp_m, spp_k, tx_m, tx_k;   // n / spp_batch and n / tiles_x as (n * m) >> k, exact for n < 2^26
     uint32_t tiles_pipe, tile_stride;    // this pipeline's l-th tile in hand-out order is its tile (l * tile_stride) % tiles_pipe (stride 1: in order)
     uint32_t tp_m, tp_k;                 // n / tiles_pipe as (n * m) >> k; tp_k == 0: hand out tile by tile (all samples of a tile in a row)
+    uint32_t tail_max;                   // live paths at or below which (with every item out) an iteration is in tail mode; 0 = never
 };
 
 // floor(n / d) for n < 2^26 with (m, k) from the host's magic_div(): k = 26 + ceil(log2 d), m = floor(2^k / d) + 1.
@@ -183,9 +186,12 @@ __global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScen
     if (off0 == 0 && threadIdx.x == 0) {              // first block of the shard: next iteration's counters
         WfShard *n = &ctr[(it + 1u) % RT_WF_RING].sh[shard];
         n->count_in = n_surv + n_new; n->n_surv = 0; n->cursor = 0;
+        const uint32_t room_all = s_sum[1], surv_all = s_sum[2];
+        const uint32_t issued = room_all < left ? room_all : left;
+        // (every shard's first block writes the same answer into its own line, so a kernel reads it with the counters it reads anyway)
+        // (the value counts the tail iterations: 1 for the first one)
+        n->tail_mode = (item_head + issued == w.n_items && surv_all + issued != 0u && surv_all + issued <= w.tail_max) ? c->sh[shard].tail_mode + 1u : 0u;
         if (shard == 0) {
-            const uint32_t room_all = s_sum[1], surv_all = s_sum[2];
-            const uint32_t issued = room_all < left ? room_all : left;
             n->item_head = item_head + issued;
             status[0] = surv_all + issued; status[1] = item_head + issued; status[2] = it + 1u;
         }
@@ -272,12 +278,13 @@ __global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScen
 #endif
 template <bool STATS, int EXT>
 __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DScene sc, PathQ q, WfCounters *ctr, uint32_t it, uint32_t cap, uint32_t lds_depth,
-                                                          StackEntry *ovf, unsigned long long *stats) {
+                                                          StackEntry *ovf, unsigned long long *stats, uint32_t with_tail) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const Stack stack{(LdsStackPtr)lds_stack + tid, 256u, lds_depth, ovf ? ovf + (size_t)blockIdx.x * 256u + tid : nullptr, gridDim.x * 256u};
     const uint32_t shard = blockIdx.x % RT_WF_SHARDS;
     WfShard *c = &ctr[it % RT_WF_RING].sh[shard];
+    if (with_tail && c->tail_mode) return;       // wf_tail_kernel runs this iteration
     const uint32_t n = c->count_in, shard_base = shard * cap;
     Counters cnt{};
     uint32_t w_next = 0, w_end = 0;
@@ -372,13 +379,13 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
 #endif
 template <bool STATS, int EXT>
 __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene sc_in, WfArgs w, PathQ cur, PathQ nxt, WfCounters *ctr, uint32_t it,
-                                                       float4 *__restrict__ samples, unsigned long long *stats, uint32_t *pixel_rays) {
+                                                       float4 *__restrict__ samples, unsigned long long *stats, uint32_t *pixel_rays, uint32_t with_tail) {
     DScene sc = sc_in;
     const uint32_t shard = blockIdx.y, off0 = blockIdx.x * blockDim.x;   // block-uniform; grid as in wf_generate_kernel
     uint32_t i = shard * w.cap + off0 + threadIdx.x;
     WfShard *c = &ctr[it % RT_WF_RING].sh[shard];
     const uint32_t n = c->count_in;
-    if (off0 >= n) return;   // block-uniform
+    if (off0 >= n || (with_tail && c->tail_mode)) return;   // block-uniform (tail mode: wf_tail_kernel runs this iteration)
     Counters cnt{};
     const V3 background = v3(w.a.bg[0], w.a.bg[1], w.a.bg[2]);
     bool survive = false, walk = false;
@@ -485,24 +492,37 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
 /* ------------------------------------------------------------------ tail */
 
 // The last paths of a batch.  Once every item has been handed out the pool only shrinks, and a few long paths keep it
-// alive for dozens of iterations that each cost three launches' worth of fixed time.  This kernel is launched between
-// iterations; it does nothing (one counter read per wave) until all items are out and at most tail_max paths live, then
-// runs each of them to its end in one lane — the walk, the shade and begin_trace of every remaining bounce, the same
-// functions in the same order, hence the same bits — parks the samples and marks the entries dead, so the next
-// iteration finds an empty pool.  One wave per block: a block's waves would only wait for each other.
+// alive for dozens of iterations that each cost three launches' worth of fixed time (the traverse launch lasts as long as the
+// longest single walk among its rays).  In "tail mode" (WfShard::tail_mode, decided by the previous generate: all items out, at
+// most tail_max paths live) an iteration is run by this kernel instead of traverse + shade: a lane takes one path through up to
+// max_bounces bounces — the walk, the shade and begin_trace of each, the same functions in the same order, hence the same bits —
+// without any launch boundary, so a bounce costs a wave the longest walk among ITS 64 rays; what is still alive then is appended to
+// the next pool buffer exactly as shade does it (compacted: the next tail iteration deals full sets again, the lanes of the
+// paths that ended in between are not carried along).  Launched in every iteration the host marks (with_tail of traverse and
+// shade); a no-op (one counter read per wave) outside tail mode.  Its waves are independent of each other.
 template <bool STATS, int EXT>
-__global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ q, const WfCounters *ctr, uint32_t it, uint32_t tail_max,
-                                                     uint32_t set_lanes, uint32_t lds_depth, StackEntry *ovf, float4 *__restrict__ samples, uint32_t *status,
+__global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ q, PathQ nxt, WfCounters *ctr, uint32_t it, uint32_t first_bounces,
+                                                     uint32_t later_bounces, uint32_t set_lanes_max, uint32_t thin_below, uint32_t lds_depth, StackEntry *ovf, float4 *__restrict__ samples,
                                                      unsigned long long *stats, uint32_t *pixel_rays) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wpb = blockDim.x >> 6;
     const uint32_t gw = blockIdx.x * wpb + (threadIdx.x >> 6), n_gw = gridDim.x * wpb;   // this wave among all waves of the launch
-    const WfCounters *c = ctr + (it % RT_WF_RING);      // written by the generate before this launch, by nobody during it
+    WfCounters *c = ctr + (it % RT_WF_RING);            // this iteration's counters: count_in fixed, n_surv appended to below
+    const uint32_t nth = c->sh[0].tail_mode;
+    if (!nth) return;                                   // the same answer in every block
+    // the first tail iteration is short: most of what is alive when the tail begins ends within a few bounces, and the survivors
+    // are worth re-dealing into full waves; from then on little ends (what lives that long lives to the depth limit)
+    const uint32_t max_bounces = nth == 1u ? first_bounces : later_bounces;
     const uint32_t my_count = c->sh[lane].count_in;     // lane s looks at shard s
-    uint32_t live = wave_sum(my_count);
-    live = (uint32_t)__shfl((int)live, 0, 64);
-    if (live == 0u || live > tail_max || c->sh[0].item_head != w.n_items) return;      // the same answer in every block
-    if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 0u;   // what the next generate would report
+    // Paths per wave: 64 while that makes more than thin_below waves (the launch is then bound by instruction issue, and a full
+    // wave is the cheapest way to issue); fewer when the paths are few (the launch is then bound by its slowest wave, and a bounce
+    // costs a wave the longest walk among its rays: the fewer rays, the shorter)
+    uint32_t set_lanes = set_lanes_max;
+    {
+        uint32_t live = wave_sum(my_count);
+        live = (uint32_t)__shfl((int)live, 0, 64);
+        while (set_lanes > 8u && (live + set_lanes / 2u - 1u) / (set_lanes / 2u) <= thin_below) set_lanes >>= 1;
+    }
     // The live paths sit unevenly in the shards (a shard holds neighbouring tiles: sky dies at once, a glass sphere lives to the
     // depth limit), so the sets of 64 paths are numbered through all shards and dealt to the waves of the launch round-robin.
     uint32_t sets_incl = (my_count + set_lanes - 1u) / set_lanes;          // inclusive prefix sum of the shards' set counts
@@ -553,10 +573,9 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
                     tv.sp = 0;
                     tv.ref = sc.root_ref;
                 }
-                q.ray_d[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));      // dead: traverse and shade skip it
             }
         }
-        while (__ballot(alive) != 0ull) {
+        for (uint32_t bounce = 0; bounce < max_bounces && __ballot(alive) != 0ull; ++bounce) {
             RG_BEGIN(RG_TRAV_ALL);
             {      // the walk, as wf_traverse_kernel does it without the refill: leaves put aside, RT_WF_NODE_STEPS node steps per turn
                 const bool walking = alive && walk;
@@ -609,6 +628,9 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
             }
             RG_END(RG_BEGIN_ALL);
         }
+        // what is still alive goes on in the next iteration: appended to the set's own shard of the next buffer (as shade does)
+        const uint32_t pos = shard * w.cap + wave_append(&c->sh[shard].n_surv, alive);
+        if (alive) store_entry(nxt, pos, p, tv, walk);
     }
     if (kTimers && !STATS) {   // development builds: the kernel's own timers apart from the pipeline's (stats + 64)
         const unsigned long long dt = __builtin_readcyclecounter() - tail_t0;

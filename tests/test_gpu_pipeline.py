@@ -59,10 +59,13 @@ def test_reference_image_matches_the_oracle(rt, gpu, book2):
     {"RT_WF_POOL_LOG2": 15, "RT_WF_PIPES": 1},
     {"RT_WF_LDS_DEPTH": 3},                        # almost the whole traversal stack in the HBM overflow area
     {"RT_WF_SAMPLES_MB": 1},                       # 64 Ki samples per batch -> several batches, several folds
-    {"RT_WF_TAIL": 0},                             # no wf_tail_kernel: the last paths go through the pipeline to their end
-    {"RT_WF_TAIL": 32768, "RT_WF_TAIL_BLOCK": 64, "RT_WF_TAIL_EVERY": 1},   # (default: 131072 paths, 256 threads, every 2nd iteration)
+    {"RT_WF_TAIL": 0},                             # no tail iterations: the last paths go through traverse + shade to their end
+    {"RT_WF_TAIL": 32768, "RT_WF_TAIL_BLOCK": 64, "RT_WF_TAIL_EVERY": 1},   # (default: 131072 paths, 256 threads; 4 bounces in the first tail iteration, 64 in the later ones)
     {"RT_WF_TAIL": 256, "RT_WF_TAIL_BLOCK": 128, "RT_WF_TAIL_EVERY": 3},    # ... a launch of 68 waves
     {"RT_WF_TAIL": 1000000},                       # ... everything that is left once all items are out: its waves take several sets each
+    {"RT_WF_TAIL_BOUNCES": 1, "RT_WF_TAIL_BOUNCES2": 1},      # a tail iteration per bounce
+    {"RT_WF_TAIL_BOUNCES": 3, "RT_WF_TAIL_BOUNCES2": 5, "RT_WF_TAIL_THIN": 0, "RT_WF_POOL_LOG2": 15},   # always 64 paths per wave; the pool refilled many times
+    {"RT_WF_TAIL_BOUNCES": 1000, "RT_WF_TAIL_THIN": 60000},   # everything in one tail iteration, 8 paths per wave
     {"RT_WF_TAIL": 3000, "RT_WF_LDS_DEPTH": 3, "RT_WF_PIPES": 1},   # ... with its stack in the overflow area
     {"RT_WF_TAIL": 20000, "RT_WF_TAIL_SET": 16},   # ... 16 paths per wave
     {"RT_WF_TILE_STRIDE": 1, "RT_WF_SAMPLE_MAJOR": 0},   # items handed out tile by tile in raster order (default: sample-major along a golden-section stride)
@@ -101,7 +104,7 @@ def test_counting_variant_traces_the_same_paths(gpu, book2):
 
 
 def test_tail_kernel_changes_no_bit(rt, gpu, book2):
-    # every scene finishes its last paths in wf_tail_kernel by default; here one without a BVH walk (Cornell: 13 leaves, flat scan)
+    # every scene runs its last iterations in wf_tail_kernel by default; here one without a BVH walk (Cornell: 13 leaves, flat scan)
     scene, params, camera, sampler = rt.configs.build("C2", image_width=64, samples_per_pixel=36)
     gpu.upload_scene(scene.flatten())
     gpu.upload_sampler(sampler)
