@@ -205,6 +205,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     if (spp_batch_max * per_sample >= (1ull << 32)) spp_batch_max = ((1ull << 32) - 1) / per_sample;
     if (spp_batch_max > (size_t)a.spp_count) spp_batch_max = (size_t)a.spp_count;
     const bool has_bvh = ctx->sc.root_ref != RT_BVH_EMPTY;
+    ctx->sc.noise_coop = (uint32_t)env_size("RT_NOISE_COOP", 32, 0, 64);   // rt_kernels.h coop_turbulence (0: every noise hit by its own lane)
     const size_t shard_q = (size_t)RT_WF_SHARDS * 256;    // pool sizes are multiples of this
     const size_t need_samples = spp_batch_max * per_sample;
     int n_pipes = (int)env_size("RT_WF_PIPES", 2, 1, kMaxPipes);

@@ -90,6 +90,7 @@ struct DScene {
     const float4 *textures;
     const uint32_t *perlin;
     const uint32_t *perlin_lds;   // Perlin table 0 staged in LDS by the shade kernel (null elsewhere)
+    uint32_t noise_coop;          // a wave with at most this many noise-texture hits evaluates them with all its lanes (coop_turbulence); 0 = never
     const uint32_t *texels;
     const uint32_t *moving;
     const uint32_t *rects;
@@ -1115,6 +1116,57 @@ RT_DEV float perlin_turbulence(const uint32_t *tab, V3 p, int depth) {  // perli
     return fabsf(acc);
 }
 
+// The product that perlin_noise() adds for one corner (perlin.rs:38-58, :84-108): the same expression as in the loop above, so
+// the same bits.
+RT_DEV float perlin_corner_term(const uint32_t *tab, V3 p, int corner) {
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = perlin_smooth(p.x - fx), v = perlin_smooth(p.y - fy), w = perlin_smooth(p.z - fz);
+    int i = pm::f2i_sat(fx), j = pm::f2i_sat(fy), k = pm::f2i_sat(fz);
+    float uu = perlin_smooth(u), vv = perlin_smooth(v), ww = perlin_smooth(w);
+    const int di = corner >> 2, dj = (corner >> 1) & 1, dk = corner & 1;
+    uint32_t idx = tab[768 + ((uint32_t)(i + di) & 255u)] ^ tab[1024 + ((uint32_t)(j + dj) & 255u)] ^
+                   tab[1280 + ((uint32_t)(k + dk) & 255u)];
+    V3 c = v3(__uint_as_float(tab[3 * idx]), __uint_as_float(tab[3 * idx + 1]), __uint_as_float(tab[3 * idx + 2]));
+    V3 weight = v3(u - (float)di, v - (float)dj, w - (float)dk);
+    return ((float)di * uu + (1.0f - (float)di) * (1.0f - uu)) * ((float)dj * vv + (1.0f - (float)dj) * (1.0f - vv)) *
+           ((float)dk * ww + (1.0f - (float)dk) * (1.0f - ww)) * dot(c, weight);
+}
+
+RT_DEV float lane_read(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// perlin_turbulence(table, p, 7) for the lanes with `need`, computed by the whole wave.  A noise hit is 7 octaves x 8 corners of
+// dependent table look-ups, ~2 200 instructions, and a wave usually holds a handful of them (the Perlin sphere of the Book-2 scene
+// is 1-3 % of all hits): run per lane, those few lanes cost the wave the whole sequence.  Here the wave takes the hits one at a
+// time: lane 8 * o + c computes corner c of octave o (56 lanes, one term each, ~45 instructions), then the terms are added in
+// the reference's order — corners 0..7 within an octave (perlin.rs:38-58), octaves 0..6 with their weights (perlin.rs:110-123) —
+// so the value has the bits of the per-lane loop.  The point of octave o is p doubled o times, i.e. p * 2^o exactly.
+// Must be called by all 64 lanes of the wave.
+RT_DEV float coop_turbulence(const DScene &sc, unsigned long long m_need, V3 p, int table) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const int oct = (int)(lane >> 3), corner = (int)(lane & 7u);
+    const float scale = (float)(1u << oct);
+    float out = 0.0f;
+    while (m_need != 0ull) {      // wave-uniform
+        const int src = __builtin_ctzll(m_need);
+        m_need &= m_need - 1ull;
+        const float px = lane_read(p.x, src), py = lane_read(p.y, src), pz = lane_read(p.z, src);
+        const int tb = __builtin_amdgcn_readlane(table, src);
+        const uint32_t *tab = (sc.perlin_lds && tb == 0) ? sc.perlin_lds : sc.perlin + (size_t)tb * RT_PERLIN_WORDS;
+        const float term = perlin_corner_term(tab, v3(px * scale, py * scale, pz * scale), corner);
+        float accum = 0.0f;       // perlin_noise of this lane's octave: the eight terms in corner order
+#pragma unroll
+        for (int c = 0; c < 8; ++c) accum += __shfl(term, (int)(lane & ~7u) + c, 64);
+        float acc = 0.0f, weight = 1.0f;
+#pragma unroll
+        for (int o = 0; o < 7; ++o) {
+            acc = acc + weight * lane_read(accum, 8 * o);
+            weight *= 0.5f;
+        }
+        if ((int)lane == src) out = fabsf(acc);
+    }
+    return out;
+}
+
 template <int EXT = EXT_ALL>
 RT_DEV bool texture_needs_uv(const DScene &sc, int tex) {
     if (!(EXT & EXT_IMAGE)) return false;     // u, v only matter to an image texture
@@ -1131,8 +1183,9 @@ RT_DEV bool texture_needs_uv(const DScene &sc, int tex) {
     return true;
 }
 
+// (have_turb: `turb` is perlin_turbulence(p, 7) for the texture itself if that is a noise texture — coop_turbulence)
 template <bool STATS, int EXT = EXT_ALL>
-RT_DEV V3 texture_value(const DScene &sc, int tex, float u, float v, V3 p, Counters &cnt) {
+RT_DEV V3 texture_value(const DScene &sc, int tex, float u, float v, V3 p, Counters &cnt, bool have_turb = false, float turb = 0.0f) {
     for (int level = 0; level < 16; ++level) {
         float4 a = sc.textures[2 * tex], b = sc.textures[2 * tex + 1];
         int type = f2i(a.x);
@@ -1146,7 +1199,8 @@ RT_DEV V3 texture_value(const DScene &sc, int tex, float u, float v, V3 p, Count
         }
         if ((EXT & EXT_NOISE) && type == RTG_TEX_NOISE) {  // noise_texture.rs:28-30
             const uint32_t *tab = (sc.perlin_lds && f2i(b.x) == 0) ? sc.perlin_lds : sc.perlin + (size_t)f2i(b.x) * RT_PERLIN_WORDS;
-            float k = 1.0f + pm::sinf_(b.z * p.z + 10.0f * perlin_turbulence(tab, p, 7));
+            const float tu = (have_turb && level == 0) ? turb : perlin_turbulence(tab, p, 7);
+            float k = 1.0f + pm::sinf_(b.z * p.z + 10.0f * tu);
             float g = 1.0f * 0.5f;
             return v3(g * k, g * k, g * k);
         }
@@ -1287,12 +1341,12 @@ RT_DEV float schlick(float cosine, float ior) {  // types.rs:165-169
 // its texture + 1, and for a solid colour words 2..4 hold that colour: most bounces then need no texture fetch
 // (one link less in the slot -> material -> texture chain of dependent loads).
 template <bool STATS, int EXT = EXT_ALL>
-RT_DEV V3 material_texture(const DScene &sc, float4 ma, float4 mb, float u, float v, V3 p, Counters &cnt) {
+RT_DEV V3 material_texture(const DScene &sc, float4 ma, float4 mb, float u, float v, V3 p, Counters &cnt, bool have_turb = false, float turb = 0.0f) {
     if (f2i(mb.w) == RTG_TEX_SOLID + 1) {
         if (STATS) cnt.tex_evals[RTG_TEX_SOLID] += 1;
         return v3(ma.z, ma.w, mb.x);
     }
-    return texture_value<STATS, EXT>(sc, f2i(ma.y), u, v, p, cnt);
+    return texture_value<STATS, EXT>(sc, f2i(ma.y), u, v, p, cnt, have_turb, turb);
 }
 
 struct Path {
@@ -1309,14 +1363,17 @@ struct Path {
 // pdf_value from inside the light, sphere.rs:95-99) makes the sample NaN, not black: the forward form has to say so as well.
 RT_DEV void end_on_black(Path &ps) { ps.radiance = ps.radiance + ps.throughput * v3(0.0f, 0.0f, 0.0f); }
 
+template <bool STATS, int EXT>
+RT_DEV bool shade_material(const DScene &sc, Path &ps, const Rec &rec, float4 ma, float4 mb, rts::Rng &rng, Counters &cnt, bool have_turb, float turb);
+
+// The hit record of `best` and its material record.  Returns false for a miss (the background is added, camera.rs:305).
 template <bool STATS, int EXT = EXT_ALL>
-RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background, rts::Rng &rng, Counters &cnt) {
+RT_DEV bool shade_record(const DScene &sc, Path &ps, const Hit &best, V3 background, Rec &rec, float4 &ma, float4 &mb, Counters &cnt) {
     if (best.id < 0) {
         ps.radiance = ps.radiance + ps.throughput * background;
         return false;
     }
     if (STATS) cnt.accepted += 1;
-    Rec rec;
     if ((EXT & EXT_MEDIA) && best.slot < 0) {  // ConstantMedium record (constant_medium.rs:85-93)
         uint32_t m = (uint32_t)(-best.slot - 1);
         float4 mb = sc.media[2 * m + 1];
@@ -1343,7 +1400,40 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
         rec = slot_record<EXT>(sc, (uint32_t)best.slot, ps.ray, best.t, want_uv, 0.001f, INFINITY);
         RG_END(RG_RECORD);
     }
-    float4 ma = sc.materials[2 * rec.material], mb = sc.materials[2 * rec.material + 1];
+    ma = sc.materials[2 * rec.material]; mb = sc.materials[2 * rec.material + 1];
+    return true;
+}
+
+// ray_color's body for the lanes with `alive` (camera.rs:264-308); true while the path continues (ps.ray is then the scattered ray
+// and ps.depth one less).  Called by ALL lanes of the wave: between the hit record and the material switch the wave evaluates the
+// noise textures among its hits together (coop_turbulence).
+template <bool STATS, int EXT = EXT_ALL>
+RT_DEV bool shade_hit(const DScene &sc, bool alive, Path &ps, const Hit &best, V3 background, rts::Rng &rng, Counters &cnt) {
+    Rec rec;
+    rec.p = v3(0.0f, 0.0f, 0.0f); rec.normal = rec.p; rec.t = 0.0f; rec.u = 0.0f; rec.v = 0.0f; rec.front_face = false; rec.material = 0;
+    float4 ma = make_float4(0.0f, 0.0f, 0.0f, 0.0f), mb = ma;
+    bool hit = false;
+    if (alive) hit = shade_record<STATS, EXT>(sc, ps, best, background, rec, ma, mb, cnt);
+    bool have_turb = false;
+    float turb = 0.0f;
+    if ((EXT & EXT_NOISE) && sc.noise_coop) {
+        const bool need = hit && f2i(mb.w) == RTG_TEX_NOISE + 1;
+        const unsigned long long m = __ballot(need);
+        if (m != 0ull && (uint32_t)__popcll(m) <= sc.noise_coop) {
+            RG_BEGIN(RG_TEXTURE);
+            int table = 0;
+            if (need) table = f2i(sc.textures[2 * f2i(ma.y) + 1].x);
+            turb = coop_turbulence(sc, m, rec.p, table);
+            have_turb = need;
+            RG_END(RG_TEXTURE);
+        }
+    }
+    if (!hit) return false;
+    return shade_material<STATS, EXT>(sc, ps, rec, ma, mb, rng, cnt, have_turb, turb);
+}
+
+template <bool STATS, int EXT>
+RT_DEV bool shade_material(const DScene &sc, Path &ps, const Rec &rec, float4 ma, float4 mb, rts::Rng &rng, Counters &cnt, bool have_turb, float turb) {
     int mtype = f2i(ma.x);
     if (STATS) cnt.shades[mtype < 5 ? mtype : 4] += 1;
     const Ray &r = ps.ray;
@@ -1351,7 +1441,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
     case RTG_MAT_DIFFUSE_LIGHT: {  // diffuse_light.rs:43-56; scatter = None -> return emitted
         RG_BEGIN(RG_EMIT);
         if (rec.front_face) {
-            V3 e = material_texture<STATS, EXT>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
+            V3 e = material_texture<STATS, EXT>(sc, ma, mb, rec.u, rec.v, rec.p, cnt, have_turb, turb);
             ps.radiance = ps.radiance + ps.throughput * e;
         } else {
             end_on_black(ps);
@@ -1393,7 +1483,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
         if (!(EXT & EXT_MEDIA)) return false;     // (only a ConstantMedium carries this material)
         RG_BEGIN(RG_ISO);
         V3 dir = random_in_unit_sphere(rng);
-        V3 att = material_texture<STATS, EXT>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
+        V3 att = material_texture<STATS, EXT>(sc, ma, mb, rec.u, rec.v, rec.p, cnt, have_turb, turb);
         ps.throughput = ps.throughput * att;
         ps.ray = Ray{rec.p, dir, rec.t};  // sic: time = hit t
         RG_END(RG_ISO);
@@ -1402,7 +1492,7 @@ RT_DEV bool shade_hit(const DScene &sc, Path &ps, const Hit &best, V3 background
     default: {  // Lambertian: lambertian.rs:33-51 + camera.rs:271-301
         RG_BEGIN(RG_LAMBERT);
         RG_BEGIN(RG_TEXTURE);
-        V3 albedo = material_texture<STATS, EXT>(sc, ma, mb, rec.u, rec.v, rec.p, cnt);
+        V3 albedo = material_texture<STATS, EXT>(sc, ma, mb, rec.u, rec.v, rec.p, cnt, have_turb, turb);
         RG_END(RG_TEXTURE);
         Onb uvw = onb_from(rec.normal);
         V3 dir;

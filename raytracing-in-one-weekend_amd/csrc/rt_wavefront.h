@@ -448,6 +448,7 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
 #endif
     const bool alive = (flags & WF_ALIVE) != 0u;
     phase_count<STATS>(cnt, PH_SHADE, alive);
+    bool cont = false;
     if (alive) {
         RG_BEGIN(RG_LOAD);
         const float4 o = cur.ray_o[i], th = cur.thr[i], h = cur.hit[i];
@@ -466,9 +467,11 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
         RG_BEGIN(RG_FINISH);
         finish_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, tv, cnt);
         RG_END(RG_FINISH);
-        RG_BEGIN(RG_SHADE_ALL);
-        const bool cont = shade_hit<STATS, EXT>(sc, p.ps, tv.best, background, p.rng, cnt);
-        RG_END(RG_SHADE_ALL);
+    }
+    RG_BEGIN(RG_SHADE_ALL);
+    cont = shade_hit<STATS, EXT>(sc, alive, p.ps, tv.best, background, p.rng, cnt);     // (all lanes: the wave shares its noise hits)
+    RG_END(RG_SHADE_ALL);
+    if (alive) {
         if (cont && p.ps.depth > 0) survive = true;
         else {
             if (cont) end_on_black(p.ps);      // the next call would return black at depth 0 (camera.rs:260)
@@ -609,9 +612,9 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
             phase_count<STATS>(cnt, PH_SHADE, alive);
             bool survive = false;
             RG_BEGIN(RG_SHADE_ALL);
+            if (alive) finish_trace<STATS, EXT>(sc, p.ps.ray, T_MIN, INFINITY, tv, cnt);
+            const bool cont = shade_hit<STATS, EXT>(sc, alive, p.ps, tv.best, background, p.rng, cnt);
             if (alive) {
-                finish_trace<STATS, EXT>(sc, p.ps.ray, T_MIN, INFINITY, tv, cnt);
-                const bool cont = shade_hit<STATS, EXT>(sc, p.ps, tv.best, background, p.rng, cnt);
                 survive = cont && p.ps.depth > 0;
                 if (!survive) {
                     if (cont) end_on_black(p.ps);

@@ -68,6 +68,9 @@ def test_reference_image_matches_the_oracle(rt, gpu, book2):
     {"RT_WF_TAIL_BOUNCES": 1000, "RT_WF_TAIL_THIN": 60000},   # everything in one tail iteration, 8 paths per wave
     {"RT_WF_TAIL": 3000, "RT_WF_LDS_DEPTH": 3, "RT_WF_PIPES": 1},   # ... with its stack in the overflow area
     {"RT_WF_TAIL": 20000, "RT_WF_TAIL_SET": 16},   # ... 16 paths per wave
+    {"RT_NOISE_COOP": 0},                          # every Perlin-noise hit evaluated by its own lane (default: a wave shares up to 32 of them, coop_turbulence)
+    {"RT_NOISE_COOP": 64, "RT_WF_TAIL": 0},        # ... always by the whole wave
+    {"RT_NOISE_COOP": 1, "RT_WF_TAIL_THIN": 60000, "RT_WF_TAIL_BOUNCES": 1000},   # ... in tail waves of 8 paths
     {"RT_WF_TILE_STRIDE": 1, "RT_WF_SAMPLE_MAJOR": 0},   # items handed out tile by tile in raster order (default: sample-major along a golden-section stride)
     {"RT_WF_TILE_STRIDE": 7},
     {"RT_WF_SAMPLE_MAJOR": 0, "RT_WF_PIPES": 3, "RT_WF_POOL_LOG2": 15},
