@@ -128,6 +128,19 @@ def test_tail_kernel_changes_no_bit(rt, gpu, book2):
         gpu.upload_sampler(sm3)
 
 
+@pytest.mark.parametrize("depth", [1, 2, 5, 9])
+def test_tail_iterations_respect_a_short_depth_limit(gpu, book2, depth):
+    # a tail iteration takes several bounces at once: a path must still stop where its depth runs out (camera.rs:258-262)
+    scene, params, camera, sampler, ref = book2
+    p = params.replace(max_ray_depth=depth)
+    with knobs(RT_WF_TAIL=0):
+        want, st0 = gpu.render(p, camera, stats=True)
+    got, st1 = gpu.render(p, camera, stats=True)
+    assert same_bits(got, want) and st0["rays"] == st1["rays"] and st1["rays"] <= depth * st1["paths"]
+    with knobs(RT_WF_TAIL_BOUNCES=1000, RT_WF_TAIL=1000000):
+        assert same_bits(gpu.render(p, camera)[0], want)
+
+
 def test_depth_zero_and_empty_ranges(rt, gpu, book2):
     scene, params, camera, sampler, ref = book2
     out = np.full_like(ref, 3.0)
