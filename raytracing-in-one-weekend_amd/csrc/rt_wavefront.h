@@ -11,6 +11,8 @@
 //               from the pool as soon as enough of them have finished their ray
 //   shade     : ray_color's body for the hit found (camera.rs:264-308); survivors are compacted
 //               into the other pool buffer, finished paths park their radiance in the sample buffer
+//   tail      : takes the place of traverse + shade once every item is out and few paths are left: several bounces
+//               of every remaining path in one launch, a lane per path, survivors compacted like shade's
 //   fold      : pixel_color += ray_color, in sample order (camera.rs:195-250), from the sample buffer
 //
 // Every path consumes its own RNG stream in the reference's call order, whatever lane, wave or
