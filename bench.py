@@ -139,14 +139,28 @@ class Bench:
             dist.barrier()
         torch.cuda.synchronize()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        # N > 1: the exchange of frame k runs on a stream of its own, behind that frame's render, while frame k + 1 renders into
+        # the other of two accumulation buffers (the collective is a copy over xGMI, the render is compute: they overlap);
+        # every reduce is inside the timed region (barrier + device synchronize below)
+        accs = [acc, torch.zeros_like(acc)] if self.comm is not None else [acc]
+        comm_stream = torch.cuda.Stream(device=dev) if self.comm is not None else None
+        rendered = [torch.cuda.Event() for _ in accs]
+        reduced = [torch.cuda.Event() for _ in accs]
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(steps):
-            acc.zero_()
+            b = k % len(accs)
+            if self.comm is not None and k >= len(accs):
+                self.stream.wait_event(reduced[b])        # the reduce of the frame that used this buffer last has read it
+            accs[b].zero_()
             ev[k][0].record(self.stream)
-            gpu.render_device(params, camera, acc.data_ptr(), sptr, spp_begin=spp_begin, spp_count=spp_count)
+            gpu.render_device(params, camera, accs[b].data_ptr(), sptr, spp_begin=spp_begin, spp_count=spp_count)
             ev[k][1].record(self.stream)
             if self.comm is not None:
-                self.comm.reduce_to_root(acc.data_ptr(), acc.numel(), 0, sptr)
+                rendered[b].record(self.stream)
+                comm_stream.wait_event(rendered[b])
+                self.comm.reduce_to_root(accs[b].data_ptr(), accs[b].numel(), 0, comm_stream.cuda_stream)
+                reduced[b].record(comm_stream)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -162,7 +176,7 @@ class Bench:
         if self.world == 1:
             a, b = acc.cpu().numpy(), count_img.cpu().numpy()
             assert np.array_equal(np.nan_to_num(a), np.nan_to_num(b)), "timed kernel and counting kernel disagree"
-        del acc, count_img
+        del acc, accs, count_img
         flops = algorithmic_flops(st)
         # HBM-side bytes per step: PMC passes of this very workload (tools/pmc.sh), committed under profiles/
         traffic, traffic_src = None, None
@@ -178,7 +192,7 @@ class Bench:
             "ms_per_step": elapsed / steps * 1e3,
             "config": {"workload": "%s %s %dx%d, %d spp per GPU (%d total), depth %d" % (
                 name, rt.configs.WORKLOADS[name]["scene"], W, H, spp_count, total_spp, params.max_ray_depth),
-                "sharding": ("sample ranges per GPU + RCCL reduce to rank 0" + (", fixed frame" if args.strong else "")) if self.world > 1 else "single GPU",
+                "sharding": ("sample ranges per GPU + RCCL reduce to rank 0, overlapped with the next frame's render" + (", fixed frame" if args.strong else "")) if self.world > 1 else "single GPU",
                 "seed": rt.configs.SEED, "primitives": int(flat.desc.n_prims), "bvh_nodes": int(info["n_bvh_nodes"]),
                 "bvh": "built on the GPU (%s) in %.2f ms (host flatten %.2f s)" % (args.device_bvh, info["bvh_build_ms"], t_flat) if info["built_on_device"]
                        else "built on the host in %.2f s (flatten)" % t_flat},
