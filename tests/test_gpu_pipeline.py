@@ -95,6 +95,19 @@ def test_sample_ranges_and_tiles_compose_bit_exactly(gpu, book2):
     assert same_bits(tiled, ref)
 
 
+def test_tiny_windows_equal_the_frame(gpu, book2):
+    # one 8x8 tile, a window inside one tile, two tiles, a one-pixel column: single-pipeline paths, hand-out stride 1
+    scene, params, camera, sampler, ref = book2
+    W, H = params.image_width, params.image_height
+    for tile in ((8, 8, 16, 16), (3, 5, 7, 6), (40, 8, 56, 16), (W - 1, 0, W, H), (0, H - 2, 23, H)):
+        out = np.zeros_like(ref)
+        gpu.render(params, camera, tile=tile, out=out)
+        x0, y0, x1, y1 = tile
+        assert same_bits(out[y0:y1, x0:x1], ref[y0:y1, x0:x1]), tile
+        out[y0:y1, x0:x1] = 0
+        assert not out.any(), "pixels outside %r were written" % (tile,)
+
+
 def test_counting_variant_traces_the_same_paths(gpu, book2):
     scene, params, camera, sampler, ref = book2
     got, st, rays = gpu.render(params, camera, stats=True, want_pixel_rays=True)
