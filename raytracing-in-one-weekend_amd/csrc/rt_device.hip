@@ -323,6 +323,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         uint32_t it_end;          // (once items_out) no path can be alive after this iteration
         bool items_out;           // the host has seen a status with every item handed out: the pool only shrinks from there
         bool drained;
+        uint32_t known_out;       // items handed out as of the last status the host has seen
     } pipe[kMaxPipes];
     for (int q = 0; q < n_pipes; ++q) {
         Pipe &P = pipe[q];
@@ -352,10 +353,14 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             // pipe q renders the tiles t with t % n_pipes == q: whole tiles, so an item's index is the same with any number of pipes
             w.pipe = (uint32_t)q; w.n_pipes = (uint32_t)n_pipes;
             w.tiles_pipe = (n_tiles - (uint32_t)q + (uint32_t)n_pipes - 1u) / (uint32_t)n_pipes;
-            w.tile_stride = tile_stride_for(w.tiles_pipe);
+            // the balanced hand-out order (rt_wavefront.h) pays where traverse blocks wait for each other; a scene that is all
+            // always-list (Cornell, Blocks) or nearly so (GeometricPrimitives: 7 quadrics and a tree of a dozen nodes) keeps raster
+            // order, which is kinder to its texture and sample-buffer accesses (+6 % there)
+            const bool balanced = has_bvh && ctx->n_bvh_nodes >= 64u;
+            w.tile_stride = (balanced || getenv("RT_WF_TILE_STRIDE")) ? tile_stride_for(w.tiles_pipe) : 1u;
             w.tail_max = tail_max;
             w.tp_m = 0; w.tp_k = 0;
-            if (env_size("RT_WF_SAMPLE_MAJOR", 1, 0, 1)) magic_div(w.tiles_pipe, &w.tp_m, &w.tp_k);
+            if (env_size("RT_WF_SAMPLE_MAJOR", balanced ? 1 : 0, 0, 1)) magic_div(w.tiles_pipe, &w.tp_m, &w.tp_k);
             w.n_items = w.tiles_pipe * spp_batch * 64u;
             const size_t items_up = ((size_t)w.n_items + shard_q - 1) / shard_q * shard_q;
             w.pool = (uint32_t)(items_up < ctx->wf_pool_entries ? items_up : ctx->wf_pool_entries);
@@ -366,7 +371,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             P.items_out = w.n_items <= w.pool;
             P.trav_blocks = trav_blocks;
             HIP_TRY(ctx, hipMemsetAsync(P.ctr, 0, (RT_WF_RING + 1) * sizeof(WfCounters), P.s));
-            P.it = 0; P.groups = 0; P.drained = false;
+            P.it = 0; P.groups = 0; P.drained = false; P.known_out = 0;
             P.it_end = P.items_out ? (uint32_t)(a.max_depth > 0 ? a.max_depth : 0) + 1u : 0xffffffffu;
             hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, w, P.Q[1], P.ctr, P.it,
                                ctx->wf_samples, P.d_status, d_stats, d_rays);
@@ -378,7 +383,10 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             // may this iteration be a tail iteration (the kernels decide from the counters: WfShard::tail_mode)?  Once the host
             // knows that every item is out: each one; before that every tail_every-th, so that a batch whose status the host has
             // not seen yet does not wait for it
-            const uint32_t with_tail = tail_max && (P.items_out || (int)(it % (uint32_t)tail_every) == tail_every - 1) ? 1u : 0u;
+            // ... and not at all while more than a few pool fills of items are still to be handed out (a tail launch that finds
+            // nothing to do still has to wait for registers and LDS to come free, which stalls its pipeline)
+            const bool near_end = (uint64_t)(P.w.n_items - P.known_out) <= 8ull * (uint64_t)P.w.pool;
+            const uint32_t with_tail = tail_max && (P.items_out || (near_end && (int)(it % (uint32_t)tail_every) == tail_every - 1)) ? 1u : 0u;
             if (has_bvh) hipLaunchKernelGGL(trav_kernel, dim3(P.trav_blocks), dim3(256), lds, P.s, ctx->sc, cur, P.ctr, it, P.w.cap,
                                             lds_depth, P.ovf, d_stats, with_tail);
             hipLaunchKernelGGL(K.shade, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
@@ -407,6 +415,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                     const uint32_t *hs = P.h_status + 4 * (group & 1);
                     if (debug) fprintf(stderr, "[rt] pipe %d after iteration %u: %u paths live, %u of %u items out\n", q, hs[2], hs[0], hs[1], P.w.n_items);
                     if (hs[0] == 0u && hs[1] == P.w.n_items) { P.drained = true; --live; continue; }
+                    P.known_out = hs[1];
                     if (p->cancel && *p->cancel) { (void)hipDeviceSynchronize(); return fail(ctx, RT_E_CANCELLED, "cancelled"); }
                     if (hs[3] != 0xffffffffu) {   // every item is out and the largest shard held hs[3] paths: the pool only shrinks from there,
                         // so the grids shrink with it (an empty iteration then costs a few microseconds, not 3 x 15).  A path loses one
