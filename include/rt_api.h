@@ -99,8 +99,9 @@ enum rt_prim_type {
  *           or, for any other boundary (a Block / rectangle / sphere under Translate / RotateY): [7] i: 1 and
  *           [0] i: first boundary slot  [1] i: number of boundary slots — slots behind the always-list that no tree or
  *           list refers to (primitive id -1); boundary.hit() is the list fold over them (constant_medium.rs:52-58)
- * light     [0] i: rt_prim_type (sphere or rect)  [1..5] q0 (+k for rects);  type 255 = an object that
- *           keeps the trait defaults of hittable.rs:47-53 (pdf_value 0, random = unit_x)
+ * light     [0] i: rt_prim_type (sphere, moving sphere or rect)  [1..5] q0 (+k for rects);  type 255 = an object that
+ *           keeps the trait defaults of hittable.rs:47-53 (pdf_value 0, random = unit_x).  Moving sphere (objects/sphere.rs:204-226):
+ *           [1..3] center(0), where pdf_value tests the ray  [4] radius  [5..7] center(time1) - center(time0), what random aims at
  * material  [0] i: rtg_material_type [1] i: texture [2..4] colour [5] fuzz [6] ior
  * texture   [0] i: rtg_texture_type [1..3] colour [4] i: odd | perlin | texel offset
  *           [5] i: even | width  [6] repeat | scale  [7] i: height

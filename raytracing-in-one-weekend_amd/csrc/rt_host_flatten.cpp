@@ -347,8 +347,24 @@ struct Flattener {
             break;
         case RTG_TRANSLATE: case RTG_ROTATE_Y: case RTG_TRANSFORM:   // transform.rs:48-54, 146-152, 206-212
             return light(g->children[n.child_begin], depth + 1);
-        case RTG_MOVING_SPHERE: case RTG_LIST: case RTG_CYLINDER:
-            return fail("MovingSphere / Cylinder / nested list in `lights` is not supported");
+        case RTG_MOVING_SPHERE: {   // objects/sphere.rs:204-226: pdf_value tests the ray at time 0, i.e. against center(0); random aims at
+            // center(time1) - center(time0) (sic: the difference of the two centres, not a centre).  Both points are computed here
+            // with the reference's expression (sphere.rs:144-147), so the kernels only ever see a sphere at one place and one target
+            const float *c0 = n.f, *c1 = n.f + 3;
+            const float time0 = n.f[6], time1 = n.f[7];
+            auto center = [&](float time, float out[3]) {
+                const float s = (time - time0) / (time1 - time0);
+                for (int a = 0; a < 3; ++a) out[a] = c0[a] + s * (c1[a] - c0[a]);
+            };
+            float at0[3], a1[3], a0[3];
+            center(0.0f, at0); center(time1, a1); center(time0, a0);
+            rec[0] = i2f(RT_PRIM_MOVING_SPHERE);
+            rec[1] = at0[0]; rec[2] = at0[1]; rec[3] = at0[2]; rec[4] = n.f[8];
+            for (int a = 0; a < 3; ++a) rec[5 + a] = a1[a] - a0[a];
+            break;
+        }
+        case RTG_LIST: case RTG_CYLINDER:
+            return fail("Cylinder / nested list in `lights` is not supported");
         default:
             rec[0] = i2f(255);
             break;

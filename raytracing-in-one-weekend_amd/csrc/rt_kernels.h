@@ -1272,8 +1272,8 @@ RT_DEV V3 lights_random(const DScene &sc, V3 origin, rts::Rng &rng) {
     int idx = rts::random_int(rng, 0, (int)sc.n_lights - 1);
     float4 a = sc.lights[2 * idx], b = sc.lights[2 * idx + 1];
     int type = f2i(a.x);
-    if (type == RT_PRIM_SPHERE) {  // sphere.rs:107-112
-        V3 direction = v3(a.y, a.z, a.w) - origin;
+    if (type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE) {  // sphere.rs:107-112; :221-226 for a MovingSphere, whose target is center(time1) - center(time0) (sic)
+        V3 direction = (type == RT_PRIM_SPHERE ? v3(a.y, a.z, a.w) : v3(b.y, b.z, b.w)) - origin;
         float distance_squared = length_squared(direction);
         Onb uvw = onb_from(direction);
         return onb_local(uvw, random_to_sphere(rng, b.x, distance_squared));
@@ -1298,7 +1298,7 @@ RT_DEV float lights_pdf_value(const DScene &sc, V3 origin, V3 v, Counters &cnt) 
         int type = f2i(a.x);
         float val = 0.0f;
         if (STATS) cnt.light_pdf_evals += 1;
-        if (type == RT_PRIM_SPHERE) {  // sphere.rs:91-105
+        if (type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE) {  // sphere.rs:91-105; :204-219: a MovingSphere where it is at time 0
             float t;
             V3 c = v3(a.y, a.z, a.w);
             if (sphere_roots(c, b.x, r, 0.001f, RT_F32_MAX, &t)) {

@@ -366,3 +366,35 @@ def test_wrapped_lights_forward_their_pdf_untransformed(rt, gpu):
     g_img, c_img, _ = compare_images(rt, gpu, O.OracleScene(s), params, camera, sampler)
     nan = np.isnan(g_img[..., :3]).any(-1)
     assert np.array_equal(nan, np.isnan(c_img[..., :3]).any(-1)) and 0 < nan.mean() < 0.9
+
+
+@pytest.mark.gpu
+def test_moving_sphere_in_lights(rt, gpu):
+    """MovingSphere::pdf_value tests the ray against the sphere at time 0 and ::random aims at center(time1) - center(time0), the
+    difference of the two centres (objects/sphere.rs:204-226, sic).  Against the oracle, ray counts equal; time0 != 0 so that
+    center(0) is an extrapolation."""
+    s = rt.host.Scene()
+    grey, red = s.lambertian(s.solid(0.7, 0.7, 0.7)), s.lambertian(s.solid(0.7, 0.2, 0.2))
+    lamp, dark = s.diffuse_light(s.solid(12, 11, 9)), s.diffuse_light(s.solid(0, 0, 0))
+    c0, c1, t0, t1, r = (1.0, 4.0, 0.5), (2.5, 4.5, -0.5), 0.25, 1.0, 0.6
+    world = [s.xz_rect(-20, 20, -20, 20, 0, grey), s.sphere((-2, 1, 0), 1, red), s.block((1, 0, -1), (2.5, 1.5, 0.5), grey),
+             s.moving_sphere(c0, c1, t0, t1, r, lamp)]
+    lights = [s.moving_sphere(c0, c1, t0, t1, r, dark), s.xz_rect(-1, 1, -1, 1, 6, dark)]
+    s.set_roots(s.hittable_list(world), s.hittable_list(lights))
+    flat = s.flatten()
+    assert flat.desc.n_lights == 2
+    rec = np.ctypeslib.as_array(flat.desc.lights, (2 * 8,))[:8].copy()
+    f = np.float32
+    at = lambda t: np.array(c0, f) + ((f(t) - f(t0)) / (f(t1) - f(t0))) * (np.array(c1, f) - np.array(c0, f))
+    assert rec[:1].view(np.int32)[0] == 1 and np.array_equal(rec[1:4], at(0.0)) and rec[4] == f(r)       # RT_PRIM_MOVING_SPHERE, center(0)
+    assert np.array_equal(rec[5:8], at(t1) - at(t0))
+    params = rt.host.RaytracerConfig.load().scene_params("CornellBox").replace(
+        image_width=96, aspect_ratio=1.5, samples_per_pixel=16, look_from=(0.0, 3.0, 11.0), look_at=(0.5, 1.5, 0.0),
+        vertical_fov=40.0, background=(0.02, 0.02, 0.03))
+    camera, sampler = params.camera(), rt.host.MultiJitteredSampler(16)
+    gpu.upload_scene(flat)
+    gpu.upload_sampler(sampler)
+    oracle = O.OracleScene(s)
+    g_img, c_img, stats = compare_images(rt, gpu, oracle, params, camera, sampler)
+    assert stats["light_pdf_evals"] > 0 and np.nanmax(g_img[..., :3]) > 1.0
+    assert np.array_equal(np.isnan(g_img), np.isnan(c_img))
