@@ -359,6 +359,9 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             const bool balanced = has_bvh && ctx->n_bvh_nodes >= 64u;
             w.tile_stride = (balanced || getenv("RT_WF_TILE_STRIDE")) ? tile_stride_for(w.tiles_pipe) : 1u;
             w.tail_max = tail_max;
+            // the material deal of the shade kernel: not for the small feature set without a tree (Cornell-type scenes: nearly all
+            // hits are one kind there); RT_WF_SORT_BLOCKS=0 / 1 forces it
+            w.sort = (uint32_t)env_size("RT_WF_SORT_BLOCKS", (has_bvh || kernel_set_for(features) != KS_LITE) ? 1 : 0, 0, 1);
             w.tp_m = 0; w.tp_k = 0;
             if (env_size("RT_WF_SAMPLE_MAJOR", balanced ? 1 : 0, 0, 1)) magic_div(w.tiles_pipe, &w.tp_m, &w.tp_k);
             w.n_items = w.tiles_pipe * spp_batch * 64u;

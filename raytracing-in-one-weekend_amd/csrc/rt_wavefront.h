@@ -75,6 +75,7 @@ struct WfArgs {
     uint32_t spp_m, spp_k, tx_m, tx_k;   // n / spp_batch and n / tiles_x as (n * m) >> k, exact for n < 2^26
     uint32_t tiles_pipe, tile_stride;    // this pipeline's l-th tile in hand-out order is its tile (l * tile_stride) % tiles_pipe (stride 1: in order)
     uint32_t tp_m, tp_k;                 // n / tiles_pipe as (n * m) >> k; tp_k == 0: hand out tile by tile (all samples of a tile in a row)
+    uint32_t sort;                       // shade deals a block's entries to its threads in material order
     uint32_t tail_max;                   // live paths at or below which (with every item out) an iteration is in tail mode; 0 = never
 };
 
@@ -400,7 +401,9 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
     // Block-local sort by what the bounce will do (material type / miss / nothing): the 256 entries of
     // the block are dealt to the threads in key order, so most waves run one branch of ray_color's
     // material switch instead of all of them.  Which thread takes which entry changes nothing else.
-    {
+    // (not for a scene whose hits are nearly all one kind — WfArgs::sort, chosen by the host: the Cornell box is 95 % solid
+    // lambertian, and the deal costs it more than the few glass and lamp hits per wave do: +2.8 % without)
+    if (w.sort) {
         __shared__ uint32_t s_count[8][4];
         __shared__ uint16_t s_perm[256];
         __shared__ uint32_t s_perlin[(EXT & EXT_NOISE) ? RT_PERLIN_WORDS : 1];
@@ -444,6 +447,8 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
         __syncthreads();
         i = shard * w.cap + off0 + s_perm[threadIdx.x];
         if (off0 + s_perm[threadIdx.x] < n) { d = cur.ray_d[i]; flags = __float_as_uint(d.w); }
+    } else if (off0 + threadIdx.x < n) {
+        d = cur.ray_d[i]; flags = __float_as_uint(d.w);
     }
 #else
     if (off0 + threadIdx.x < n) { d = cur.ray_d[i]; flags = __float_as_uint(d.w); }

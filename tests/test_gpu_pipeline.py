@@ -68,6 +68,7 @@ def test_reference_image_matches_the_oracle(rt, gpu, book2):
     {"RT_WF_TAIL_BOUNCES": 1000, "RT_WF_TAIL_THIN": 60000},   # everything in one tail iteration, 8 paths per wave
     {"RT_WF_TAIL": 3000, "RT_WF_LDS_DEPTH": 3, "RT_WF_PIPES": 1},   # ... with its stack in the overflow area
     {"RT_WF_TAIL": 20000, "RT_WF_TAIL_SET": 16},   # ... 16 paths per wave
+    {"RT_WF_SORT_BLOCKS": 0},                      # shade without its material deal (the default for Cornell-type scenes)
     {"RT_NOISE_COOP": 0},                          # every Perlin-noise hit evaluated by its own lane (default: a wave shares up to 32 of them, coop_turbulence)
     {"RT_NOISE_COOP": 64, "RT_WF_TAIL": 0},        # ... always by the whole wave
     {"RT_NOISE_COOP": 1, "RT_WF_TAIL_THIN": 60000, "RT_WF_TAIL_BOUNCES": 1000},   # ... in tail waves of 8 paths
