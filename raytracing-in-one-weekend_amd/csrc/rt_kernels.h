@@ -1247,46 +1247,6 @@ RT_DEV V3 random_in_unit_sphere(rts::Rng &rng) {  // types.rs:95-104
     }
 }
 
-RT_DEV V3 random_cosine_direction(rts::Rng &rng) {  // types.rs:141-151
-    float r1 = rts::random_real(rng), r2 = rts::random_real(rng);
-    float z = sqrtf(1.0f - r2);
-    float phi = (float)(2.0 * 3.14159265358979323846) * r1;
-    float s, c;
-    pm::sincosf_(phi, &s, &c);
-    float sr = sqrtf(r2);
-    return v3(c * sr, s * sr, z);
-}
-
-RT_DEV V3 random_to_sphere(rts::Rng &rng, float radius, float distance_squared) {  // types.rs:153-163
-    float r1 = rts::random_real(rng), r2 = rts::random_real(rng);
-    float z = 1.0f + r2 * (sqrtf(1.0f - radius * radius / distance_squared) - 1.0f);
-    float phi = (float)(2.0 * 3.14159265358979323846) * r1;
-    float s, c;
-    pm::sincosf_(phi, &s, &c);
-    float k = sqrtf(1.0f - z * z);
-    return v3(c * k, s * k, z);
-}
-
-// lights.random(origin): hittable_list.rs:71-75 then the object's random()
-RT_DEV V3 lights_random(const DScene &sc, V3 origin, rts::Rng &rng) {
-    int idx = rts::random_int(rng, 0, (int)sc.n_lights - 1);
-    float4 a = sc.lights[2 * idx], b = sc.lights[2 * idx + 1];
-    int type = f2i(a.x);
-    if (type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE) {  // sphere.rs:107-112; :221-226 for a MovingSphere, whose target is center(time1) - center(time0) (sic)
-        V3 direction = (type == RT_PRIM_SPHERE ? v3(a.y, a.z, a.w) : v3(b.y, b.z, b.w)) - origin;
-        float distance_squared = length_squared(direction);
-        Onb uvw = onb_from(direction);
-        return onb_local(uvw, random_to_sphere(rng, b.x, distance_squared));
-    }
-    if (type == 255) return v3(1.0f, 0.0f, 0.0f);  // hittable.rs:51-53
-    // rectangles.rs:69-77 / 139-147 / 209-217: a0,a1,b0,b1,k = a.y a.z a.w b.x b.y
-    float ra = rts::random_real_range(rng, a.y, a.z);
-    float rb = rts::random_real_range(rng, a.w, b.x);
-    V3 pt = type == RT_PRIM_XY_RECT ? v3(ra, rb, b.y) : (type == RT_PRIM_XZ_RECT ? v3(ra, b.y, rb) : v3(b.y, ra, rb));
-    return pt - origin;
-}
-
-// lights.pdf_value(origin, v): hittable_list.rs:59-69
 template <bool STATS>
 RT_DEV float lights_pdf_value(const DScene &sc, V3 origin, V3 v, Counters &cnt) {
     if (sc.n_lights == 0) return 0.0f;
@@ -1495,16 +1455,46 @@ RT_DEV bool shade_material(const DScene &sc, Path &ps, const Rec &rec, float4 ma
         V3 albedo = material_texture<STATS, EXT>(sc, ma, mb, rec.u, rec.v, rec.p, cnt, have_turb, turb);
         RG_END(RG_TEXTURE);
         Onb uvw = onb_from(rec.normal);
-        V3 dir;
-        if (rts::random_real(rng) < 0.5f) {
-            RG_BEGIN(RG_L_LIGHTS);
-            dir = lights_random(sc, rec.p, rng);
-            RG_END(RG_L_LIGHTS);
-        } else {
-            RG_BEGIN(RG_L_COSINE);
-            dir = onb_local(uvw, random_cosine_direction(rng));
-            RG_END(RG_L_COSINE);
+        // MixturePdf::generate (pdf.rs:72-78): the lights' direction or the cosine one.  A sphere light (sphere.rs:107-112 +
+        // types.rs:153-163) and the cosine lobe (types.rs:141-151) are the same computation — two draws, one sincos, two square
+        // roots, a change of basis — with different arguments, so the lanes of both kinds run it together instead of one kind
+        // after the other; every lane still makes its own draws in its own order and evaluates its own expressions.
+        V3 dir = v3(1.0f, 0.0f, 0.0f);          // (a lights entry with the trait default, hittable.rs:51-53)
+        int lobe = 0;                           // 0 cosine lobe, 1 sphere light, 2 anything else in `lights`
+        Onb basis = uvw;
+        float radius = 0.0f, distance_squared = 1.0f;
+        RG_BEGIN(RG_L_LIGHTS);
+        if (rts::random_real(rng) < 0.5f) {     // lights.random(rec.p): hittable_list.rs:71-75 then the object's random()
+            lobe = 2;
+            const int idx = rts::random_int(rng, 0, (int)sc.n_lights - 1);
+            const float4 la = sc.lights[2 * idx], lb = sc.lights[2 * idx + 1];
+            const int type = f2i(la.x);
+            if (type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE) {   // :221-226 for a MovingSphere, whose target is center(time1) - center(time0) (sic)
+                const V3 direction = (type == RT_PRIM_SPHERE ? v3(la.y, la.z, la.w) : v3(lb.y, lb.z, lb.w)) - rec.p;
+                distance_squared = length_squared(direction);
+                basis = onb_from(direction);
+                radius = lb.x;
+                lobe = 1;
+            } else if (type != 255) {           // rectangles.rs:69-77 / 139-147 / 209-217: a0,a1,b0,b1,k = la.y la.z la.w lb.x lb.y
+                const float ra = rts::random_real_range(rng, la.y, la.z);
+                const float rb = rts::random_real_range(rng, la.w, lb.x);
+                const V3 pt = type == RT_PRIM_XY_RECT ? v3(ra, rb, lb.y) : (type == RT_PRIM_XZ_RECT ? v3(ra, lb.y, rb) : v3(lb.y, ra, rb));
+                dir = pt - rec.p;
+            }
         }
+        RG_END(RG_L_LIGHTS);
+        RG_BEGIN(RG_L_COSINE);
+        if (lobe != 2) {
+            const float r1 = rts::random_real(rng), r2 = rts::random_real(rng);
+            const float root_a = sqrtf(lobe == 0 ? 1.0f - r2 : 1.0f - radius * radius / distance_squared);
+            const float z = lobe == 0 ? root_a : 1.0f + r2 * (root_a - 1.0f);
+            const float phi = (float)(2.0 * 3.14159265358979323846) * r1;
+            float sn, cs;
+            pm::sincosf_(phi, &sn, &cs);
+            const float root_b = sqrtf(lobe == 0 ? r2 : 1.0f - z * z);
+            dir = onb_local(basis, v3(cs * root_b, sn * root_b, z));
+        }
+        RG_END(RG_L_COSINE);
         // MixturePdf::value (pdf.rs:68-70)
         RG_BEGIN(RG_L_PDF);
         float light_val = lights_pdf_value<STATS>(sc, rec.p, dir, cnt);
