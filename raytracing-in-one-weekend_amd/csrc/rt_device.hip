@@ -116,38 +116,42 @@ size_t env_size(const char *name, size_t dflt, size_t lo, size_t hi) {
 constexpr int KS_LITE = EXT_NONE;                               // spheres, rectangles, Translate / RotateY, solid + checker: C1, C2
 constexpr int KS_MESH = EXT_TRI | EXT_IMAGE;                    // + triangle meshes and image textures: C4
 constexpr int KS_BOOK2 = EXT_NOISE | EXT_MEDIA | EXT_IMAGE;     // + Perlin noise, media, image textures: C3, C5
-constexpr int KS_FULL = EXT_ALL;                                // + quadrics and general Transforms
+constexpr int KS_FULL = EXT_ALL & ~EXT_CHAIN;                   // + quadrics and general Transforms
+constexpr int KS_CHAIN = EXT_ALL;                               // + wrappers nested in any order (chains of xform records)
 int kernel_set_for(int need) {
     if ((need & ~KS_LITE) == 0) return KS_LITE;
     if ((need & ~KS_MESH) == 0) return KS_MESH;
     if ((need & ~KS_BOOK2) == 0) return KS_BOOK2;
-    return KS_FULL;
+    if ((need & ~KS_FULL) == 0) return KS_FULL;
+    return KS_CHAIN;
 }
 template <bool STATS> struct WfKernels {
-    decltype(&wf_generate_kernel<STATS, KS_FULL>) generate;
-    decltype(&wf_shade_kernel<STATS, KS_FULL>) shade;
-    decltype(&wf_tail_kernel<STATS, KS_FULL>) tail;
+    decltype(&wf_generate_kernel<STATS, KS_CHAIN>) generate;
+    decltype(&wf_shade_kernel<STATS, KS_CHAIN>) shade;
+    decltype(&wf_tail_kernel<STATS, KS_CHAIN>) tail;
     decltype(&wf_traverse_kernel<STATS, EXT_NONE>) traverse;
 };
 template <bool STATS, int KS> WfKernels<STATS> wf_kernels_of(bool tree_has_xform, bool tree_has_tris) {
+    constexpr int XF = EXT_XFORM | EXT_TRI | (KS & EXT_CHAIN);
     WfKernels<STATS> k;
     k.generate = wf_generate_kernel<STATS, KS>;
     k.shade = wf_shade_kernel<STATS, KS>;
     k.tail = wf_tail_kernel<STATS, KS>;
     // the walk's leaf step: spheres and rectangles, + triangles, + slots under a general Transform
-    k.traverse = tree_has_xform ? wf_traverse_kernel<STATS, EXT_XFORM | EXT_TRI> : tree_has_tris ? wf_traverse_kernel<STATS, EXT_TRI> : wf_traverse_kernel<STATS, EXT_NONE>;
+    k.traverse = tree_has_xform ? wf_traverse_kernel<STATS, XF> : tree_has_tris ? wf_traverse_kernel<STATS, EXT_TRI> : wf_traverse_kernel<STATS, EXT_NONE>;
     return k;
 }
 template <bool STATS> WfKernels<STATS> wf_kernels(int features, bool tree_has_xform) {
     const bool tris = (features & EXT_TRI) != 0;
     if constexpr (STATS) {
-        return wf_kernels_of<STATS, KS_FULL>(tree_has_xform, tris);
+        return wf_kernels_of<STATS, KS_CHAIN>(tree_has_xform, tris);
     } else {
         switch (kernel_set_for(features)) {
         case KS_LITE: return wf_kernels_of<STATS, KS_LITE>(tree_has_xform, tris);
         case KS_MESH: return wf_kernels_of<STATS, KS_MESH>(tree_has_xform, tris);
         case KS_BOOK2: return wf_kernels_of<STATS, KS_BOOK2>(tree_has_xform, tris);
-        default: return wf_kernels_of<STATS, KS_FULL>(tree_has_xform, tris);
+        case KS_FULL: return wf_kernels_of<STATS, KS_FULL>(tree_has_xform, tris);
+        default: return wf_kernels_of<STATS, KS_CHAIN>(tree_has_xform, tris);
         }
     }
 }
@@ -264,7 +268,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     int per_cu = 0;
     // two instances of the traversal kernel: scenes with a general Transform inside the BVH need the code for it in the leaf step
     int features = ctx->features;
-    if (const char *e = getenv("RT_KERNEL_SET")) { if (!strcmp(e, "full")) features = EXT_ALL; }   // A/B: run a scene on the full set
+    if (const char *e = getenv("RT_KERNEL_SET")) { if (!strcmp(e, "full")) features |= KS_FULL; }   // A/B: run a scene on the full set
     const WfKernels<STATS> K = wf_kernels<STATS>(features, ctx->bvh_has_general_xform);
     auto *const trav_kernel = K.traverse;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel, 256, lds));
@@ -607,19 +611,34 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         int type = w4 & 15, xf = (w4 >> 8) - 1;
         if (type > RT_PRIM_HYPERBOLOID) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "slot %u: primitive type %d", i, type);
         if (xf >= (int)s->n_xforms) return fail(ctx, RT_E_INVALID, "slot %u: xform out of range", i);
-        bool general = false;
+        bool general = false, chain = false;
         if (xf >= 0) {
             int32_t flags, m;
             memcpy(&flags, &s->xforms[(size_t)xf * RT_REC_FLOATS], 4);
             memcpy(&m, &s->xforms[(size_t)xf * RT_REC_FLOATS + 1], 4);
-            general = (flags & 4) != 0;
-            if (general && (m < 0 || (uint32_t)m >= s->n_matrices || !s->matrices)) return fail(ctx, RT_E_INVALID, "slot %u: matrix out of range", i);
+            general = (flags & 12) != 0;     // a general Transform or a chain: kernels with EXT_XFORM
+            auto matrix_ok = [&](int32_t mi) { return mi >= 0 && (uint32_t)mi < s->n_matrices && s->matrices; };
+            if ((flags & 4) && !matrix_ok(m)) return fail(ctx, RT_E_INVALID, "slot %u: matrix out of range", i);
+            chain = (flags & 8) != 0;
+            if (chain) {                     // a run of 2..8 plain records
+                int32_t count;
+                memcpy(&count, &s->xforms[(size_t)xf * RT_REC_FLOATS + 2], 4);
+                if (flags != 8 || m < 0 || count < 2 || count > 8 || (uint64_t)m + (uint64_t)count > s->n_xforms)
+                    return fail(ctx, RT_E_INVALID, "slot %u: xform chain outside the xform array", i);
+                for (int32_t k = m; k < m + count; ++k) {
+                    int32_t f2, m2;
+                    memcpy(&f2, &s->xforms[(size_t)k * RT_REC_FLOATS], 4);
+                    memcpy(&m2, &s->xforms[(size_t)k * RT_REC_FLOATS + 1], 4);
+                    if ((f2 & ~7) || ((f2 & 4) && !matrix_ok(m2))) return fail(ctx, RT_E_INVALID, "slot %u: xform chain entry %d is not a plain record", i, k);
+                }
+            }
         }
         const bool in_always = i >= s->always_begin && i - s->always_begin < s->always_count;
         // quadrics may accept hits below t_min (cone.rs:61-65): the traversal kernels do not carry their code
         if (type >= RT_PRIM_CYLINDER && !in_always) return fail(ctx, RT_E_INVALID, "slot %u: quadrics must be in the always-list", i);
         general_in_bvh |= general && !in_always;
         if (general) need |= EXT_XFORM;
+        if (chain) need |= EXT_CHAIN;
         if (type >= RT_PRIM_CYLINDER) need |= EXT_QUADRICS;
         if (type == RT_PRIM_TRIANGLE) need |= EXT_TRI;
         if (mat < 0 || (uint32_t)mat >= s->n_materials) return fail(ctx, RT_E_INVALID, "slot %u: material out of range", i);
@@ -669,7 +688,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
             const int type = w4 & 15, xf = (w4 >> 8) - 1;
             int32_t flags = 0;
             if (xf >= 0) memcpy(&flags, &s->xforms[(size_t)xf * RT_REC_FLOATS], 4);
-            if (!(type == RT_PRIM_SPHERE || (type >= RT_PRIM_XY_RECT && type <= RT_PRIM_YZ_RECT)) || (flags & 4))
+            if (!(type == RT_PRIM_SPHERE || (type >= RT_PRIM_XY_RECT && type <= RT_PRIM_YZ_RECT)) || (flags & 12))
                 return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "medium %u: boundary slot %d is not a sphere or rectangle under Translate / RotateY", i, k);
         }
         int32_t tex, tkind;

@@ -44,12 +44,20 @@ struct Attr {
 
 inline float i2f(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
 
-struct Wrap {
-    bool flip = false;       // parity of FlipFace wrappers that act after the last Translate
+// One xform record's worth of wrappers: Translate(RotateY(.)), either of the two alone, or one general Transform.
+struct WrapOp {
     bool has_rot = false, has_trans = false;
     float sin_t = 0, cos_t = 1;
     float off[3] = {0, 0, 0};
     int matrix = -1;         // general Transform (transform.rs:155-213): index into rth_flat::matrices
+};
+// The wrappers between the world and a leaf, outermost first.  Any nesting of Translate / RotateY / Transform is a
+// sequence of WrapOps: a RotateY directly under a Translate shares that Translate's op (the Cornell-box pattern, one
+// record as before); everything else opens a new op, and more than one op becomes a chain record (rt_api.h).
+struct Wrap {
+    bool flip = false;       // parity of FlipFace wrappers with no Translate above them
+    bool any_trans = false;
+    std::vector<WrapOp> ops;
 };
 
 }  // namespace
@@ -84,15 +92,15 @@ struct Flattener {
     // their medium's record; they take no primitive id (rt_scene_graph.h) and appear in no tree or list
     std::vector<Slot> boundary;
     bool boundary_mode = false;
+    static constexpr size_t kMaxOps = 8;   // xform records per chain (rt_api.h)
 
     bool fail(const std::string &m) {
         if (err.empty()) err = m;
         return false;
     }
 
-    int xform_index(const Wrap &w) {
-        if (!w.has_rot && !w.has_trans && w.matrix < 0) return -1;
-        float rec[RT_REC_FLOATS] = {};
+    static void op_record(const WrapOp &w, float rec[RT_REC_FLOATS]) {
+        for (int i = 0; i < RT_REC_FLOATS; ++i) rec[i] = 0.0f;
         if (w.matrix >= 0) {
             rec[0] = i2f(4); rec[1] = i2f(w.matrix);
         } else {
@@ -100,33 +108,53 @@ struct Flattener {
             rec[1] = w.sin_t; rec[2] = w.cos_t;
             rec[3] = w.off[0]; rec[4] = w.off[1]; rec[5] = w.off[2];
         }
-        for (size_t i = 0; i + RT_REC_FLOATS <= out->xforms.size(); i += RT_REC_FLOATS)
-            if (memcmp(&out->xforms[i], rec, sizeof rec) == 0) return (int)(i / RT_REC_FLOATS);
-        out->xforms.insert(out->xforms.end(), rec, rec + RT_REC_FLOATS);
-        return (int)(out->xforms.size() / RT_REC_FLOATS) - 1;
+    }
+    // index of `n` consecutive records equal to `recs` in out->xforms, appended if there is no such run yet
+    int xform_run(const float *recs, size_t n) {
+        const size_t len = n * RT_REC_FLOATS;
+        for (size_t i = 0; i + len <= out->xforms.size(); i += RT_REC_FLOATS)
+            if (memcmp(&out->xforms[i], recs, len * sizeof(float)) == 0) return (int)(i / RT_REC_FLOATS);
+        out->xforms.insert(out->xforms.end(), recs, recs + len);
+        return (int)((out->xforms.size() - len) / RT_REC_FLOATS);
+    }
+    int xform_index(const Wrap &w) {
+        if (w.ops.empty()) return -1;
+        std::vector<float> recs(w.ops.size() * RT_REC_FLOATS);
+        for (size_t k = 0; k < w.ops.size(); ++k) op_record(w.ops[k], &recs[k * RT_REC_FLOATS]);
+        const int first = xform_run(recs.data(), w.ops.size());
+        if (w.ops.size() == 1) return first;
+        // chain record: the ops of the run are applied to the ray outermost first, to the hit record in reverse
+        float rec[RT_REC_FLOATS] = {i2f(8), i2f(first), i2f((int32_t)w.ops.size())};
+        return xform_run(rec, 1);
     }
 
-    // Object-space box -> world box through RotateY then Translate (the wrappers' own
-    // bounding_box code is not followed: any conservative box serves the traversal).
-    Box to_world(const Box &b, const Wrap &w) {
-        Box r;
-        r.reset();
-        for (int i = 0; i < 8; ++i) {
-            float p[3] = {(i & 1) ? b.hi[0] : b.lo[0], (i & 2) ? b.hi[1] : b.lo[1], (i & 4) ? b.hi[2] : b.lo[2]};
-            if (w.matrix >= 0) {
-                const float *m = &out->matrices[(size_t)w.matrix * RT_MATRIX_FLOATS + 12];   // obj2world
-                float q[3];
-                for (int a = 0; a < 3; ++a) q[a] = m[4 * a] * p[0] + m[4 * a + 1] * p[1] + m[4 * a + 2] * p[2] + m[4 * a + 3];
-                for (int a = 0; a < 3; ++a) p[a] = q[a];
+    // Object-space box -> world box through the wrappers, innermost first; inside one op RotateY then Translate (the
+    // wrappers' own bounding_box code is not followed: any conservative box serves the traversal).  The box of the eight
+    // transformed corners is taken after every op, so it contains what the ops make of any point of the object's box.
+    Box to_world(const Box &b, const Wrap &wr) {
+        Box cur = b;
+        for (size_t k = wr.ops.size(); k-- > 0;) {
+            const WrapOp &w = wr.ops[k];
+            Box r;
+            r.reset();
+            for (int i = 0; i < 8; ++i) {
+                float p[3] = {(i & 1) ? cur.hi[0] : cur.lo[0], (i & 2) ? cur.hi[1] : cur.lo[1], (i & 4) ? cur.hi[2] : cur.lo[2]};
+                if (w.matrix >= 0) {
+                    const float *m = &out->matrices[(size_t)w.matrix * RT_MATRIX_FLOATS + 12];   // obj2world
+                    float q[3];
+                    for (int a = 0; a < 3; ++a) q[a] = m[4 * a] * p[0] + m[4 * a + 1] * p[1] + m[4 * a + 2] * p[2] + m[4 * a + 3];
+                    for (int a = 0; a < 3; ++a) p[a] = q[a];
+                }
+                if (w.has_rot) {
+                    float x = w.cos_t * p[0] + w.sin_t * p[2], z = -w.sin_t * p[0] + w.cos_t * p[2];
+                    p[0] = x; p[2] = z;
+                }
+                if (w.has_trans) for (int a = 0; a < 3; ++a) p[a] += w.off[a];
+                r.add(p);
             }
-            if (w.has_rot) {
-                float x = w.cos_t * p[0] + w.sin_t * p[2], z = -w.sin_t * p[0] + w.cos_t * p[2];
-                p[0] = x; p[2] = z;
-            }
-            if (w.has_trans) for (int a = 0; a < 3; ++a) p[a] += w.off[a];
-            r.add(p);
+            cur = r;
         }
-        return r;
+        return cur;
     }
 
     void emit(int type, const Wrap &w, int material, const float q0[4], float scalar, const float q2[4], const Box &obj_box,
@@ -231,12 +259,14 @@ struct Flattener {
         }
         case RTG_TRANSFORM: {
             if (n.child_count != 1) return fail("Transform needs one child");
-            if (w.has_trans || w.has_rot || w.matrix >= 0) return fail("unsupported wrapper nesting: Transform under Translate/RotateY/Transform");
+            if (w.ops.size() >= kMaxOps) return fail("more than 8 nested Translate / RotateY / Transform wrappers");
             M4 o2w = m4_identity(), w2o;
             memcpy(o2w.a, n.f, 12 * sizeof(float));
             if (!m4_invert(o2w, &w2o)) return fail("Matrix is not invertible");          // transform.rs:166
             M4 n2w = m4_transpose(m4_adjoint(w2o));                                       // transform.rs:171
-            w.matrix = (int)(out->matrices.size() / RT_MATRIX_FLOATS);
+            WrapOp op;
+            op.matrix = (int)(out->matrices.size() / RT_MATRIX_FLOATS);
+            w.ops.push_back(op);
             out->matrices.insert(out->matrices.end(), w2o.a, w2o.a + 12);
             out->matrices.insert(out->matrices.end(), o2w.a, o2w.a + 12);
             out->matrices.insert(out->matrices.end(), n2w.a, n2w.a + 12);
@@ -244,26 +274,37 @@ struct Flattener {
         }
         case RTG_FLIP_FACE:
             // A FlipFace under a Translate is overwritten by Translate's HitRecord::new
-            // (transform.rs:36-44), so only flips met before the Translate count.  Transform keeps the
-            // inner front_face (transform.rs:198-202), so a flip on either side of it counts.
+            // (transform.rs:36-44), so only flips with no Translate above them count.  RotateY and Transform keep the
+            // inner front_face (transform.rs:136-143, 198-202), so a flip on either side of them counts.
             if (n.child_count != 1) return fail("FlipFace needs one child");
-            if (!w.has_trans) w.flip = !w.flip;
+            if (!w.any_trans) w.flip = !w.flip;
             return walk(ch[0], w, depth + 1);
         case RTG_TRANSLATE:
             if (n.child_count != 1) return fail("Translate needs one child");
-            if (w.has_trans || w.has_rot || w.matrix >= 0) return fail("unsupported wrapper nesting: Translate under Translate/RotateY/Transform");
-            w.has_trans = true;
-            w.off[0] = n.f[0]; w.off[1] = n.f[1]; w.off[2] = n.f[2];
+        {
+            if (w.ops.size() >= kMaxOps) return fail("more than 8 nested Translate / RotateY / Transform wrappers");
+            WrapOp op;
+            op.has_trans = true;
+            op.off[0] = n.f[0]; op.off[1] = n.f[1]; op.off[2] = n.f[2];
+            w.ops.push_back(op);
+            w.any_trans = true;
             return walk(ch[0], w, depth + 1);
+        }
         case RTG_ROTATE_Y: {
             if (n.child_count != 1) return fail("RotateY needs one child");
-            if (w.has_rot || w.matrix >= 0) return fail("unsupported wrapper nesting: RotateY under RotateY/Transform");
-            if (n.i[0] == 1) { w.sin_t = n.f[1]; w.cos_t = n.f[2]; }   // rth_add_rotate_y_sincos: the host's own values
+            // directly under a Translate: that Translate's op takes the rotation too (one record for Translate(RotateY(.)))
+            const bool joins = !w.ops.empty() && w.ops.back().has_trans && !w.ops.back().has_rot && w.ops.back().matrix < 0;
+            if (!joins) {
+                if (w.ops.size() >= kMaxOps) return fail("more than 8 nested Translate / RotateY / Transform wrappers");
+                w.ops.push_back(WrapOp{});
+            }
+            WrapOp &op = w.ops.back();
+            if (n.i[0] == 1) { op.sin_t = n.f[1]; op.cos_t = n.f[2]; }   // rth_add_rotate_y_sincos: the host's own values
             else {
                 float rads = (n.f[0] * 3.14159265358979323846f) / 180.0f;  // types.rs:44-46
-                pm::sincosf_(rads, &w.sin_t, &w.cos_t);
+                pm::sincosf_(rads, &op.sin_t, &op.cos_t);
             }
-            w.has_rot = true;
+            op.has_rot = true;
             return walk(ch[0], w, depth + 1);
         }
         case RTG_BVH: case RTG_LIST:
@@ -272,7 +313,7 @@ struct Flattener {
             return true;
         case RTG_CONSTANT_MEDIUM: {
             if (n.child_count != 1) return fail("ConstantMedium needs one boundary");
-            if (w.has_rot || w.has_trans || w.flip || w.matrix >= 0) return fail("ConstantMedium under a wrapper is not supported");
+            if (!w.ops.empty() || w.flip) return fail("ConstantMedium under a wrapper is not supported");
             const rtg_node &b = g->nodes[ch[0]];
             if (b.type == RTG_SPHERE) {
                 float rec[RT_REC_FLOATS] = {b.f[0], b.f[1], b.f[2], b.f[3], -1.0f / n.f[0] /* constant_medium.rs:24 */,
@@ -300,6 +341,12 @@ struct Flattener {
             const bool ok = walk(ch[0], Wrap{}, depth + 1);
             boundary_mode = false;
             if (!ok) return false;
+            for (size_t k = first; k < boundary.size(); ++k) {
+                int32_t w4, fl = 0;
+                memcpy(&w4, &boundary[k].w[4], 4);
+                if ((w4 >> 8) > 0) memcpy(&fl, &out->xforms[(size_t)((w4 >> 8) - 1) * RT_REC_FLOATS], 4);
+                if (fl & 8) return fail("ConstantMedium boundary under more than one Translate(RotateY(.)) is not supported");
+            }
             float rec[RT_REC_FLOATS] = {i2f((int32_t)first) /* + the number of other slots, added when the slot array is laid out */,
                                         i2f((int32_t)(boundary.size() - first)), 0.0f, 0.0f, -1.0f / n.f[0], i2f(n.material), i2f((int32_t)id), i2f(1)};
             out->media.insert(out->media.end(), rec, rec + RT_REC_FLOATS);

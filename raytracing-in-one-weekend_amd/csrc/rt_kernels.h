@@ -160,9 +160,9 @@ RT_DEV V3 mat_apply(const float4 *m, V3 v, float w) { return v3(mat_row(m[0], v,
 // (rt_api.h); the traversal kernel therefore only distinguishes "general Transform inside the tree" or not.
 enum { EXT_NONE = 0, EXT_XFORM = 1 /* general Transform */, EXT_QUADRICS = 2, EXT_NOISE = 4 /* Perlin noise texture */,
        EXT_MEDIA = 8 /* ConstantMedium + Isotropic */, EXT_TRI = 16 /* triangle meshes */, EXT_IMAGE = 32 /* image textures (u, v) */,
-       EXT_ALL = 63 };
+       EXT_CHAIN = 64 /* chains of xform records: wrappers nested in any order */, EXT_ALL = 127 };
 template <int EXT = EXT_ALL>
-RT_DEV Ray to_object_rec(const DScene &sc, float4 a, float4 b, const Ray &r) {
+RT_DEV Ray to_object_one(const DScene &sc, float4 a, float4 b, const Ray &r) {
     int flags = f2i(a.x);
     float sin_t = a.y, cos_t = a.z;
     Ray q = r;
@@ -182,8 +182,47 @@ RT_DEV Ray to_object_rec(const DScene &sc, float4 a, float4 b, const Ray &r) {
     }
     return q;
 }
+// A chain record (flags 8: first, count) stands for `count` consecutive records of sc.xforms, outermost wrapper first: any
+// nesting of Translate / RotateY / Transform (each wrapper's hit() transforms the ray it is given and hands it to its child).
+// Only kernels with EXT_CHAIN carry the loops (measured: -3 % on GeometricPrimitives and Blocks if the full set carried
+// them, profiles/r2/ab_chain_records.txt); rt_scene_upload asks for that set when a slot has such a record.
+template <int EXT = EXT_ALL>
+RT_DEV Ray to_object_rec(const DScene &sc, float4 a, float4 b, const Ray &r) {
+    if ((EXT & EXT_CHAIN) && (f2i(a.x) & 8)) {
+        const int first = f2i(a.y), count = f2i(a.z);
+        Ray q = r;
+        for (int k = 0; k < count; ++k) q = to_object_one<EXT>(sc, sc.xforms[2 * (first + k)], sc.xforms[2 * (first + k) + 1], q);
+        return q;
+    }
+    return to_object_one<EXT>(sc, a, b, r);
+}
 template <int EXT = EXT_ALL>
 RT_DEV Ray to_object(const DScene &sc, int xf, const Ray &r) { return to_object_rec<EXT>(sc, sc.xforms[2 * xf], sc.xforms[2 * xf + 1], r); }
+
+// The way out of one record's wrappers for a hit record (p, face-corrected normal, front_face): Transform
+// (transform.rs:195-201), RotateY (:128-143), Translate (:35-44).  `d_in` = direction of the ray these wrappers were given.
+template <int EXT = EXT_ALL>
+RT_DEV void record_out_one(const DScene &sc, float4 xa, float4 xb, V3 d_in, V3 &p, V3 &nn, bool &front) {
+    int flags = f2i(xa.x);
+    if ((EXT & EXT_XFORM) && (flags & 4)) {   // p and normal to the outer space, front_face / t / u / v kept
+        const float4 *m = sc.matrices + 9 * (size_t)f2i(xa.y);
+        p = mat_apply(m + 3, p, 1.0f);
+        nn = normalize(mat_apply(m + 6, nn, 0.0f));
+    }
+    if (flags & 1) {
+        float sin_t = xa.y, cos_t = xa.z;
+        V3 p0 = p, n0 = nn;
+        p.x = cos_t * p0.x + sin_t * p0.z;
+        p.z = -sin_t * p0.x + cos_t * p0.z;
+        nn.x = cos_t * n0.x + sin_t * n0.z;
+        nn.z = -sin_t * n0.x + cos_t * n0.z;
+    }
+    if (flags & 2) {
+        p = p + v3(xa.w, xb.x, xb.y);
+        front = dot(d_in, nn) < 0.0f;  // transform.rs:36: HitRecord::new again (direction is unchanged by Translate)
+        nn = front ? nn : -nn;
+    }
+}
 
 // A slot as the kernels read it: all 64 bytes at once, so that the loads of a test do not wait on
 // each other.  In the DEVICE copy of the slot array, spheres and rectangles under a transform carry
@@ -514,25 +553,15 @@ RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, floa
     bool front = dot(r.d, n) < 0.0f;  // hittable.rs:26
     V3 nn = front ? n : -n;
     if (xf >= 0) {
-        int flags = f2i(xa.x);
-        if ((EXT & EXT_XFORM) && (flags & 4)) {   // transform.rs:195-201: p and normal to world space, front_face / t / u / v kept
-            const float4 *m = sc.matrices + 9 * (size_t)f2i(xa.y);
-            p = mat_apply(m + 3, p, 1.0f);
-            nn = normalize(mat_apply(m + 6, nn, 0.0f));
-        }
-        if (flags & 1) {
-            float sin_t = xa.y, cos_t = xa.z;
-            V3 p0 = p, n0 = nn;
-            p.x = cos_t * p0.x + sin_t * p0.z;
-            p.z = -sin_t * p0.x + cos_t * p0.z;
-            nn.x = cos_t * n0.x + sin_t * n0.z;
-            nn.z = -sin_t * n0.x + cos_t * n0.z;
-        }
-        if (flags & 2) {
-            p = p + v3(xa.w, xb.x, xb.y);
-            front = dot(r_world.d, nn) < 0.0f;  // transform.rs:36: HitRecord::new again (direction is unchanged by Translate)
-            nn = front ? nn : -nn;
-        }
+        if ((EXT & EXT_CHAIN) && (f2i(xa.x) & 8)) {   // chain: innermost record first; each one sees the ray its wrappers were given
+            const int first = f2i(xa.y), count = f2i(xa.z);
+            for (int k = count - 1; k >= 0; --k) {
+                Ray q = r_world;
+                for (int j = 0; j < k; ++j) q = to_object_one<EXT>(sc, sc.xforms[2 * (first + j)], sc.xforms[2 * (first + j) + 1], q);
+                record_out_one<EXT>(sc, sc.xforms[2 * (first + k)], sc.xforms[2 * (first + k) + 1], q.d, p, nn, front);
+            }
+        } else
+            record_out_one<EXT>(sc, xa, xb, r_world.d, p, nn, front);
     }
     if (w4 & 16) front = !front;  // flip_face.rs:24-27
     rec.p = p; rec.normal = nn; rec.front_face = front;
@@ -648,7 +677,7 @@ RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t
 // "while-while" traversal: every lane walks inner nodes until it stands on a leaf (or is done);
 // only then does the wave run the primitive tests, so node steps and leaf steps are not
 // serialised against each other inside one iteration.
-template <bool STATS>
+template <bool STATS, int EXT = EXT_XFORM | EXT_TRI>
 RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_id, Hit &best, const Stack &stack, Counters &cnt) {
     int32_t ref = sc.root_ref;
     if (ref == RT_BVH_EMPTY) return;
@@ -666,7 +695,7 @@ RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_
         for (uint32_t i = 0; i < count; ++i) {
             float t;
             int32_t id;
-            if (slot_hit<STATS, EXT_XFORM | EXT_TRI>(sc, first + i, r, t_min, best.t, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)(first + i));
+            if (slot_hit<STATS, EXT>(sc, first + i, r, t_min, best.t, &t, &id, cnt) && id > floor_id) consider(best, t, id, (int32_t)(first + i));
         }
         ref = pop_ref(stack, sp);
     }
@@ -831,7 +860,7 @@ RT_DEV void always_scan(const DScene &sc, const Ray &r, float t_min, float t_max
                 const int w4 = f2i(cu.meta.x), type = w4 & 15, xf = (w4 >> 8) - 1;
                 // rectangles, plain or under Translate / RotateY; one under a general Transform stays with the "other kinds"
                 // (its matrices would have to sit in vector registers per lane: 36 of them)
-                if (type < RT_PRIM_XY_RECT || type > RT_PRIM_YZ_RECT || (xf >= 0 && (f2i(cu.q2.x) & 4))) continue;
+                if (type < RT_PRIM_XY_RECT || type > RT_PRIM_YZ_RECT || (xf >= 0 && (f2i(cu.q2.x) & 12))) continue;
                 rects |= 1u << i;
                 if (STATS) cnt.prim_tests[type] += 1;
                 if (xf != frame_xf) {
@@ -957,7 +986,7 @@ RT_DEV bool closest_hit(const DScene &sc, const Ray &r, float t_min, float t_max
     // t == t_max is accepted by every leaf (e.g. `t > t_max` rejects, rectangles.rs:25), so the
     // first candidate must win even at t == t_max: start below any id.
     always_scan<STATS, EXT>(sc, r, t_min, t_max, floor_id, best, cnt);
-    traverse<STATS>(sc, r, t_min, floor_id, best, stack, cnt);
+    traverse<STATS, (EXT & EXT_CHAIN) | EXT_XFORM | EXT_TRI>(sc, r, t_min, floor_id, best, stack, cnt);
     // MovingSphere boxes cover the shutter interval only; isotropic.rs:32 can hand a ray any "time"
     if (sc.n_moving && !(r.time >= 0.0f && r.time <= 1.0f))
         for (uint32_t i = 0; i < sc.n_moving; ++i) {

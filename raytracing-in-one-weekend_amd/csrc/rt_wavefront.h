@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
                     if (m_leaf != 0ull && (n_leaf >= RT_LEAF_MIN || n_leaf * RT_LEAF_FRAC >= n_live || m_node == 0ull)) {
                         phase_count<STATS>(cnt, PH_LEAF, has_leaf);
                         RG_BEGIN(RG_LEAF);
-                        if (has_leaf) { trav_leaf_test<STATS, EXT & (EXT_XFORM | EXT_TRI)>(sc, p.ps.ray, T_MIN, tv, pend, cnt); pend = RT_BVH_EMPTY; }
+                        if (has_leaf) { trav_leaf_test<STATS, EXT & (EXT_XFORM | EXT_TRI | EXT_CHAIN)>(sc, p.ps.ray, T_MIN, tv, pend, cnt); pend = RT_BVH_EMPTY; }
                         RG_END(RG_LEAF);
                     }
                 }

@@ -286,6 +286,77 @@ def test_many_transformed_blocks_go_through_the_bvh(rt, gpu):
     assert np.array_equal(img2.view(np.uint32), img.view(np.uint32))
 
 
+def nested_wrappers_scene(rt, many):
+    """Translate / RotateY / Transform in the orders the one-record form cannot hold (transform.rs:14-213), around every
+    kind of leaf: rectangles and spheres (record inline in the slot), triangles and a moving sphere (record fetched from
+    sc.xforms), a quadric (always-list), with FlipFace at different depths."""
+    rng = np.random.default_rng(21)
+    s = rt.host.Scene()
+    # not 0.9 for green: floor x sky = 0.9 * 0.4 resolves to 153.0, a knife edge for the 8-bit comparison
+    grey = s.lambertian(s.checker(s.solid(0.2, 0.3, 0.1), s.solid(0.8, 0.85, 0.9), 3.0))
+    red = s.lambertian(s.solid(0.7, 0.2, 0.2))
+    metal = s.metal(0.8, 0.8, 0.9, 0.05)
+    glass = s.dielectric(1.5)
+    lamp = s.diffuse_light(s.solid(5, 5, 5))
+    shear = np.eye(4, dtype=np.float32); shear[0, 1] = 0.3; shear[:3, 3] = (0.5, 0.2, -0.5); shear[2, 2] = 1.4
+    scale = np.diag([0.8, 1.3, 0.8, 1.0]).astype(np.float32); scale[:3, 3] = (-2.0, 0.0, 1.0)
+    block = lambda m: s.block((-0.5, 0.0, -0.5), (0.5, 1.0, 0.5), m)
+    objs = [s.xz_rect(-1000, 1000, -1000, 1000, 0, grey)]
+    objs.append(s.rotate_y(s.translate(block(red), (3.0, 0.0, 0.0)), 35.0))                                   # R(T(.))
+    objs.append(s.translate(s.translate(s.sphere((0, 0.6, 0), 0.6, glass), (-1.0, 0.0, 2.0)), (0.5, 0.3, 0.0)))   # T(T(.))
+    objs.append(s.rotate_y(s.rotate_y(block(metal), 20.0), -50.0))                                            # R(R(.))
+    objs.append(s.transform(s.translate(s.rotate_y(block(grey), 25.0), (1.0, 0.0, -3.0)), scale))             # M(T(R(.)))
+    objs.append(s.translate(s.rotate_y(s.transform(s.sphere((0, 1, 0), 0.7, metal), shear), 60.0), (-4.0, 0.0, -1.0)))  # T(R(M(.)))
+    objs.append(s.transform(s.transform(block(red), shear), scale))                                           # M(M(.))
+    objs.append(s.translate(s.flip_face(s.rotate_y(s.flip_face(s.translate(s.sphere((0, 0.5, 0), 0.5, glass), (0, 0, 4.0))), 15.0)), (2.0, 0.0, 0.0)))
+    objs.append(s.flip_face(s.rotate_y(s.flip_face(s.transform(s.flip_face(s.translate(s.xz_rect(-2, 2, -2, 2, 7, lamp), (0.5, 0, 0))), np.eye(4, dtype=np.float32))), 10.0)))
+    objs.append(s.rotate_y(s.translate(s.moving_sphere((0, 0.4, 0), (0, 0.8, 0), 0.0, 1.0, 0.4, red), (-3.0, 0.0, 3.0)), -20.0))
+    verts = np.array([[0, 0, 0, 0, 0, 1, 0, 0], [1.5, 0, 0, 0, 0, 1, 1, 0], [0, 1.5, 0, 0, 0, 1, 0, 1], [1.5, 1.5, 0.3, 0, 0, 1, 1, 1]], np.float32)
+    idx, node = np.array([0, 1, 2, 2, 1, 3], np.uint32), np.array([[0, 6]], np.uint32)
+    objs.append(s.rotate_y(s.translate(s.triangle_mesh(verts, idx, node, None, grey), (4.0, 0.2, 1.0)), 20.0))
+    quarter = np.array([[1, 0, 0, 1.0], [0, 0, -1, 1.0], [0, 1, 0, -4.0], [0, 0, 0, 1]], np.float32)
+    objs.append(s.translate(s.transform(s.cylinder(0.5, -0.8, 0.8, 2.0 * np.pi, metal), quarter), (0.0, 0.3, 0.0)))     # T(M(quadric))
+    for i in range(40 if many else 0):       # enough leaves for a real tree, each under a chain of its own
+        pos = (float(rng.uniform(-9, 9)), 0.0, float(rng.uniform(-9, 9)))
+        inner = s.sphere((0, 0.3, 0), 0.3, s.lambertian(s.solid(*rng.uniform(0.2, 0.9, 3).tolist()))) if i % 2 else block(grey)
+        objs.append(s.rotate_y(s.translate(s.rotate_y(inner, float(rng.uniform(0, 90))), pos), float(rng.uniform(-30, 30))))
+    s.set_roots(s.hittable_list(objs), s.hittable_list([s.xz_rect(-2, 2, -2, 2, 7, s.diffuse_light(s.solid(0, 0, 0)))]))
+    params = rt.host.RaytracerConfig.load().scene_params("CornellBox").replace(
+        image_width=128, aspect_ratio=1.6, samples_per_pixel=16, look_from=(0.0, 5.0, 14.0), look_at=(0.0, 1.0, 0.0),
+        vertical_fov=42.0, background=(0.3, 0.4, 0.6))
+    return s, params
+
+
+@pytest.mark.parametrize("many", [False, True])
+def test_wrappers_nested_in_any_order(rt, gpu, many):
+    """Chains of xform records: first hits (ids, t, normal, front_face, u v) and images against the oracle, whose wrapper
+    classes nest by construction.  Without the 40 extra objects the leaves sit in a small tree; with them the chains
+    are met by the traversal kernel's Transform instance too, and on a device-built tree."""
+    s, params = nested_wrappers_scene(rt, many)
+    flat = s.flatten()
+    x = flat.xforms()
+    assert (x[:, 0].view(np.int32) == 8).sum() >= 10
+    camera = params.camera()
+    sampler = rt.host.MultiJitteredSampler(16)
+    gpu.upload_scene(flat)
+    gpu.upload_sampler(sampler)
+    oracle = O.OracleScene(s)
+    rays = primary_and_bounce_rays(rt, s, params, camera, 1 << 15)
+    g, exact = check_first_hit(gpu, oracle, rays)
+    assert exact
+    hit = g[0] != 0xFFFFFFFF
+    seen = set(g[0][hit].tolist())
+    assert {7, 20, 27, 29, 32} <= seen and seen & {30, 31}, "both spheres' kinds, the moving sphere, a triangle and the cylinder must be seen"
+    _, exact = check_first_hit(gpu, oracle, bounce_rays(rays, g[1], g[2], hit))
+    assert exact
+    img, _, st = compare_images(rt, gpu, oracle, params, camera, sampler)
+    if many:
+        assert st["node_visits"] > 0
+        gpu.upload_scene(s.flatten(device_bvh=True))
+        img2, _ = gpu.render(params, camera)
+        assert np.array_equal(img2.view(np.uint32), img.view(np.uint32))
+
+
 def test_paths_deeper_than_255_bounces(rt, gpu):
     """max_ray_depth is an unbounded i32 in the reference (camera.rs:253-262).  Inside a closed diffuse sphere with a tiny
     emitter and a zero-emission `lights` rectangle that is not in `world` (Book-1's arrangement, main.rs:187-196; here it

@@ -293,12 +293,36 @@ def test_quadrics_stay_out_of_the_bvh(rt):
     assert np.allclose(sl[42, 12:14], [1.0, 0.0])                  # x^2 + y^2 - 0 z^2 = 1: ah = 1, ch = 0
 
 
-def test_unsupported_nesting_is_reported(rt):
+def test_any_wrapper_nesting_flattens_to_chain_records(rt):
+    """Translate(RotateY(.)) and a lone wrapper stay one xform record; every other nesting of Translate / RotateY /
+    Transform (transform.rs:14-213: each hit() hands its ray to its child) becomes a chain record over a run of them."""
     s = rt.host.Scene()
     m = s.lambertian(s.solid(1, 1, 1))
-    inner = s.rotate_y(s.translate(s.sphere((0, 0, 0), 1, m), (1, 0, 0)), 10.0)
-    s.set_roots(s.hittable_list([inner]), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
-    with pytest.raises(rt.RtError) as e:
+    ball = lambda: s.sphere((0, 0, 0), 1, m)
+    objs = [s.translate(s.rotate_y(ball(), 10.0), (1, 0, 0)),                       # one record, flags 3
+            s.rotate_y(s.translate(ball(), (1, 0, 0)), 10.0),                       # chain of 2: R, T
+            s.transform(s.translate(ball(), (1, 0, 0)), np.eye(4)),                 # chain of 2: M, T
+            s.translate(s.translate(s.rotate_y(ball(), 10.0), (1, 0, 0)), (0, 2, 0)),   # chain of 2: T, T+R
+            s.rotate_y(s.translate(ball(), (1, 0, 0)), 10.0)]                       # the same chain again: shared
+    s.set_roots(s.hittable_list(objs), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
+    f = s.flatten()
+    x = f.xforms()
+    flags = x[:, 0].view(np.int32)
+    sl = f.slots()
+    by_id = {int(i): int(w >> 8) - 1 for i, w in zip(sl[:, 6].view(np.int32), sl[:, 4].view(np.int32))}
+    assert flags[by_id[0]] == 3
+    for k, kinds in ((1, [1, 2]), (2, [4, 2]), (3, [2, 3])):
+        rec = x[by_id[k]].view(np.int32)
+        assert rec[0] == 8 and rec[2] == 2
+        assert flags[rec[1]:rec[1] + 2].tolist() == kinds
+    assert by_id[4] == by_id[1]
+    assert np.allclose(x[x[by_id[3]].view(np.int32)[1], 3:6], [0, 2, 0])            # outermost first
+    # the world box follows the whole chain: R(T(ball)) sits at the rotated offset
+    deep = ball()
+    for _ in range(9):
+        deep = s.translate(deep, (1, 0, 0))
+    s.set_roots(s.hittable_list([deep]), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
+    with pytest.raises(rt.RtError) as e:                                            # at most 8 records per chain
         s.flatten()
     assert e.value.status == -5
     s = rt.host.Scene()
@@ -307,9 +331,9 @@ def test_unsupported_nesting_is_reported(rt):
         s.transform(s.sphere((0, 0, 0), 1, m), np.arange(16.0))
     with pytest.raises(rt.RtError):                                # singular: the reference asserts (mat4.rs:610)
         s.transform(s.sphere((0, 0, 0), 1, m), np.diag([1.0, 0.0, 1.0, 1.0]))
-    nested = s.transform(s.translate(s.sphere((0, 0, 0), 1, m), (1, 0, 0)), np.eye(4))
-    s.set_roots(s.hittable_list([nested]), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
-    with pytest.raises(rt.RtError):
+    smoke = s.constant_medium(s.translate(s.translate(s.block((0, 0, 0), (1, 1, 1), m), (1, 0, 0)), (1, 0, 0)), s.solid(1, 1, 1), 0.1)
+    s.set_roots(s.hittable_list([smoke]), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
+    with pytest.raises(rt.RtError):                                # a medium's boundary takes one Translate(RotateY(.)) only
         s.flatten()
 
 
