@@ -104,6 +104,10 @@ enum rt_prim_type {
  * light     [0] i: rt_prim_type (sphere, moving sphere or rect)  [1..5] q0 (+k for rects);  type 255 = an object that
  *           keeps the trait defaults of hittable.rs:47-53 (pdf_value 0, random = unit_x).  Moving sphere (objects/sphere.rs:204-226):
  *           [1..3] center(0), where pdf_value tests the ray  [4] radius  [5..7] center(time1) - center(time0), what random aims at
+ *           Cylinder (cylinder.rs:134-161): [1] zmin [2] zmax [3] phi_max [4] radius [5..7] centre of its box, what random aims at.
+ *           A HittableList inside `lights` (hittable_list.rs:59-75): type 254, [1] i: first [2] i: count (>= 1) = its members, a
+ *           run of records behind this one; `lights` with such entries starts with a record of type 253, [1] i: first
+ *           [2] i: count = the members of `lights` itself (otherwise they are records 0 .. n_lights-1); at most 4 lists deep
  * material  [0] i: rtg_material_type [1] i: texture [2..4] colour [5] fuzz [6] ior
  * texture   [0] i: rtg_texture_type [1..3] colour [4] i: odd | perlin | texel offset
  *           [5] i: even | width  [6] repeat | scale  [7] i: height

@@ -15,6 +15,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <limits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -869,8 +870,20 @@ struct Cylinder : Hittable {  // cylinder.rs
         return true;
     }
     bool bounding_box(Real, Real, Aabb *out) const override { *out = Aabb{V(-radius, -radius, zmin), V(radius, radius, zmax)}; return true; }
-    // pdf_value / random (:134-161) are not restated: no scene puts a Cylinder into `lights`, and the scene
-    // loader rejects one there.
+    Real area() const { return (zmax - zmin) * radius * phi_max; }  // :46-48
+    Real pdf_value(Vec3 o, Vec3 v) const override {  // :134-150
+        HitRecord h;
+        if (!hit(Ray{o, v, 0.0f}, 0.0001f, std::numeric_limits<Real>::infinity(), &h)) return 0.0f;
+        Real pdf = (1.0f / area()) / (std::fabs(dot(h.normal, -v)) / length_squared(o - h.p));
+        return std::isinf(pdf) ? 0.0f : pdf;
+    }
+    Vec3 random(Vec3 v) const override {  // :152-161; aabb.center() = (min + max) * 0.5, aabb3.rs:52-54
+        Vec3 center = (V(-radius, -radius, zmin) + V(radius, radius, zmax)) * 0.5f;
+        Vec3 direction = center - v;
+        Real distance_squared = length_squared(direction);
+        Onb uvw = onb_from(direction);
+        return uvw.local_from_vec(random_to_sphere(radius, distance_squared));
+    }
 };
 
 struct Cone : Hittable {  // cone.rs

@@ -644,6 +644,31 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         if (mat < 0 || (uint32_t)mat >= s->n_materials) return fail(ctx, RT_E_INVALID, "slot %u: material out of range", i);
         tris |= type == RT_PRIM_TRIANGLE;
     }
+    {   // `lights`: plain records, or a root record (253) + runs of list members (254 records point at theirs, always behind themselves)
+        std::vector<uint8_t> depth(s->n_lights, 0);     // nesting level of the list a record belongs to; 0 = belongs to none
+        auto word = [&](uint32_t i, int k) { int32_t v; memcpy(&v, &s->lights[(size_t)i * RT_REC_FLOATS + k], 4); return v; };
+        const bool rooted = word(0, 0) == 253;
+        auto claim = [&](uint32_t owner, int level) {   // the run of a 253 / 254 record
+            const int32_t first = word(owner, 1), count = word(owner, 2);
+            if (first <= (int32_t)owner || count < 1 || (uint64_t)first + (uint64_t)count > s->n_lights || level > 4) return false;
+            for (int32_t k = first; k < first + count; ++k) {
+                if (depth[k]) return false;             // a record belongs to one list
+                depth[k] = (uint8_t)level;
+            }
+            return true;
+        };
+        if (rooted && !claim(0, 1)) return fail(ctx, RT_E_INVALID, "lights: bad root record");
+        for (uint32_t i = rooted ? 1u : 0u; i < s->n_lights; ++i) {
+            const int32_t type = word(i, 0);
+            const bool known = type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE || (type >= RT_PRIM_XY_RECT && type <= RT_PRIM_YZ_RECT) ||
+                               type == RT_PRIM_CYLINDER || type == 255 || (type == 254 && rooted);
+            if (!known) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "light %u: type %d", i, type);
+            if (rooted && !depth[i]) return fail(ctx, RT_E_INVALID, "light %u belongs to no list", i);
+            if (type == 254 && !claim(i, depth[i] + 1)) return fail(ctx, RT_E_INVALID, "light %u: bad list record (members behind it, at most 4 lists deep)", i);
+            if (type == RT_PRIM_CYLINDER) need |= EXT_QUADRICS;    // its pdf_value runs the cylinder's hit test
+        }
+        if (rooted) need |= EXT_CHAIN;                  // the kernel set that carries the rarely needed loops
+    }
     if (tris && !s->tri_attrs) return fail(ctx, RT_E_INVALID, "triangles without tri_attrs");
     for (uint32_t i = 0; i < s->n_moving_slots; ++i)
         if (s->moving_slots[i] >= s->n_slots) return fail(ctx, RT_E_INVALID, "moving slot out of range");

@@ -380,10 +380,12 @@ struct Flattener {
     // lights list: pdf_value / random are forwarded WITHOUT transforming by Translate / RotateY
     // (transform.rs:48-54, 146-152); FlipFace, Block, Bvh, ... keep the trait defaults
     // (hittable.rs:47-53: pdf 0, random = unit_x) -> light type 255.
-    bool light(int32_t idx, int depth) {
+    // One record of `lights` for node idx; a nested list's members are queued and laid out behind the records made so far.
+    bool light_record(int32_t idx, int depth, float rec[RT_REC_FLOATS], int32_t *list_node) {
         if (idx < 0 || (uint32_t)idx >= g->n_nodes || depth > 64) return fail("bad light node");
         const rtg_node &n = g->nodes[idx];
-        float rec[RT_REC_FLOATS] = {};
+        for (int i = 0; i < RT_REC_FLOATS; ++i) rec[i] = 0.0f;
+        *list_node = -1;
         switch (n.type) {
         case RTG_SPHERE:
             rec[0] = i2f(RT_PRIM_SPHERE); rec[1] = n.f[0]; rec[2] = n.f[1]; rec[3] = n.f[2]; rec[4] = n.f[3];
@@ -393,7 +395,8 @@ struct Flattener {
             for (int i = 0; i < 5; ++i) rec[1 + i] = n.f[i];
             break;
         case RTG_TRANSLATE: case RTG_ROTATE_Y: case RTG_TRANSFORM:   // transform.rs:48-54, 146-152, 206-212
-            return light(g->children[n.child_begin], depth + 1);
+            if (n.child_count != 1) return fail("wrapper needs one child");
+            return light_record(g->children[n.child_begin], depth + 1, rec, list_node);
         case RTG_MOVING_SPHERE: {   // objects/sphere.rs:204-226: pdf_value tests the ray at time 0, i.e. against center(0); random aims at
             // center(time1) - center(time0) (sic: the difference of the two centres, not a centre).  Both points are computed here
             // with the reference's expression (sphere.rs:144-147), so the kernels only ever see a sphere at one place and one target
@@ -410,13 +413,60 @@ struct Flattener {
             for (int a = 0; a < 3; ++a) rec[5 + a] = a1[a] - a0[a];
             break;
         }
-        case RTG_LIST: case RTG_CYLINDER:
-            return fail("Cylinder / nested list in `lights` is not supported");
-        default:
+        case RTG_CYLINDER: {   // cylinder.rs:134-161: pdf_value from its own hit() and area(); random() aims at aabb.center()
+            // like a sphere of the cylinder's radius (aabb3.rs:52-54: (min + max) * 0.5)
+            const float radius = n.f[0], zmin = n.f[1], zmax = n.f[2];
+            rec[0] = i2f(RT_PRIM_CYLINDER);
+            rec[1] = zmin; rec[2] = zmax; rec[3] = n.f[3]; rec[4] = radius;
+            rec[5] = (-radius + radius) * 0.5f; rec[6] = (-radius + radius) * 0.5f; rec[7] = (zmin + zmax) * 0.5f;
+            break;
+        }
+        case RTG_LIST:         // hittable_list.rs:59-75: the mean of its members' pdfs; random() draws one of them
+            if (n.child_count < 1) return fail("an empty list in `lights` (the reference indexes objects[random_int(0,-1)], hittable_list.rs:71-75)");
+            rec[0] = i2f(254);
+            *list_node = idx;
+            break;
+        default:               // FlipFace, Block, Bvh, ...: the trait defaults (hittable.rs:47-53: pdf 0, random = unit_x)
             rec[0] = i2f(255);
             break;
         }
-        out->lights.insert(out->lights.end(), rec, rec + RT_REC_FLOATS);
+        return true;
+    }
+
+    // lights list: pdf_value / random are forwarded WITHOUT transforming by Translate / RotateY / Transform.  Without nested
+    // lists: one record per member, as before.  With them: a root record (253), then run after run, each list's members together.
+    bool lights(int32_t root) {
+        struct Pending { int32_t node; size_t rec; int depth; };   // a list whose members still have to be laid out; its record
+        std::vector<Pending> todo;
+        std::vector<float> recs;
+        auto lay_out = [&](int32_t list, int depth) -> bool {
+            const rtg_node &n = g->nodes[list];
+            if (depth > 4) return fail("`lights`: lists nested more than 4 deep");
+            for (int i = 0; i < n.child_count; ++i) {
+                float rec[RT_REC_FLOATS];
+                int32_t sub;
+                if (!light_record(g->children[n.child_begin + i], 0, rec, &sub)) return false;
+                if (sub >= 0) todo.push_back({sub, recs.size() / RT_REC_FLOATS, depth + 1});
+                recs.insert(recs.end(), rec, rec + RT_REC_FLOATS);
+            }
+            return true;
+        };
+        if (!lay_out(root, 1)) return false;
+        if (!todo.empty()) {                                        // nested: start again behind a root record
+            const int32_t n_top = g->nodes[root].child_count;
+            todo.clear(); recs.clear();
+            float rec[RT_REC_FLOATS] = {i2f(253), i2f(1), i2f(n_top)};
+            recs.insert(recs.end(), rec, rec + RT_REC_FLOATS);
+            if (!lay_out(root, 1)) return false;
+            for (size_t k = 0; k < todo.size(); ++k) {              // grows while it is walked
+                const Pending p = todo[k];
+                const size_t first = recs.size() / RT_REC_FLOATS;
+                if (!lay_out(p.node, p.depth)) return false;
+                recs[p.rec * RT_REC_FLOATS + 1] = i2f((int32_t)first);
+                recs[p.rec * RT_REC_FLOATS + 2] = i2f(g->nodes[p.node].child_count);
+            }
+        }
+        out->lights = recs;
         return true;
     }
 };
@@ -556,12 +606,10 @@ int rth_flatten_opts(const rtg_graph *g, uint32_t flags, rth_flat **out_flat) {
         set_error("flatten: %s", fl.err.c_str());
         return RT_E_UNSUPPORTED_PRIMITIVE;
     }
-    const rtg_node &ll = g->nodes[g->lights_root];
-    for (int i = 0; i < ll.child_count; ++i)
-        if (!fl.light(g->children[ll.child_begin + i], 0)) {
-            set_error("flatten: %s", fl.err.c_str());
-            return RT_E_UNSUPPORTED_PRIMITIVE;
-        }
+    if (!fl.lights(g->lights_root)) {
+        set_error("flatten: %s", fl.err.c_str());
+        return RT_E_UNSUPPORTED_PRIMITIVE;
+    }
     flat->n_prims = fl.next_id;
 
     // tables

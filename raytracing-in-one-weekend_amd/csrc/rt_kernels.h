@@ -1276,18 +1276,91 @@ RT_DEV V3 random_in_unit_sphere(rts::Rng &rng) {  // types.rs:95-104
     }
 }
 
-template <bool STATS>
+// pdf_value of one entry of `lights` for the ray r = (origin, v, time 0)
+template <bool STATS, int EXT = EXT_ALL>
+RT_DEV float light_pdf_one(float4 a, float4 b, const Ray &r, V3 origin, V3 v, Counters &cnt) {
+    const int type = f2i(a.x);
+    float val = 0.0f;
+    if (STATS) cnt.light_pdf_evals += 1;
+    if (type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE) {  // sphere.rs:91-105; :204-219: a MovingSphere where it is at time 0
+        float t;
+        V3 c = v3(a.y, a.z, a.w);
+        if (sphere_roots(c, b.x, r, 0.001f, RT_F32_MAX, &t)) {
+            float cos_theta_max = sqrtf(1.0f - b.x * b.x / length_squared(c - origin));
+            float solid_angle = 2.0f * 3.14159265358979323846f * (1.0f - cos_theta_max);
+            val = 1.0f / solid_angle;
+        }
+    } else if ((EXT & EXT_QUADRICS) && type == RT_PRIM_CYLINDER) {  // cylinder.rs:134-150: zmin zmax phi_max | radius
+        SlotRec cyl;
+        cyl.q0 = make_float4(b.x, a.y, a.z, a.w);
+        cyl.meta = cyl.q2 = cyl.q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        QuadHit qh;
+        if (quadric_test(RT_PRIM_CYLINDER, cyl, r, 0.0001f, __builtin_inff(), &qh)) {
+            float qu, qv;
+            const V3 n = quadric_record(RT_PRIM_CYLINDER, cyl, qh, &qu, &qv);   // |dot(n, -v)|: the record's face flip drops out
+            const float area = (a.z - a.y) * b.x * a.w;
+            const float pdf = (1.0f / area) / (fabsf(dot(n, -v)) / length_squared(origin - qh.p));
+            val = isinf(pdf) ? 0.0f : pdf;
+        }
+    } else if (type != 255) {  // rectangles.rs:54-67
+        float t, pa, pb;
+        float4 q0 = make_float4(a.y, a.z, a.w, b.x);
+        if (rect_test(type, q0, b.y, r, 0.001f, RT_F32_MAX, &t, &pa, &pb)) {
+            int AX = type == RT_PRIM_XY_RECT ? 2 : (type == RT_PRIM_XZ_RECT ? 1 : 0);
+            V3 n = v3(AX == 0 ? 1.0f : 0.0f, AX == 1 ? 1.0f : 0.0f, AX == 2 ? 1.0f : 0.0f);
+            bool front = dot(v, n) < 0.0f;
+            V3 nn = front ? n : -n;
+            float area = (q0.y - q0.x) * (q0.w - q0.z);
+            float distance_squared = t * t * length_squared(v);
+            float cosine = fabsf(dot(v, nn) / length(v));
+            val = distance_squared / (cosine * area);
+        }
+    }
+    return val;
+}
+
+// HittableList::pdf_value of `lights` (hittable_list.rs:59-69): sum + weight * pdf over the members, in order.  Lists inside
+// the list (records 254 under a root record 253, rt_api.h) are the same fold one level down, started at 0 and added to the
+// outer sum as one member: an explicit stack of at most 4 folds, in the kernel set with EXT_CHAIN only.
+template <bool STATS, int EXT = EXT_ALL>
 RT_DEV float lights_pdf_value(const DScene &sc, V3 origin, V3 v, Counters &cnt) {
     if (sc.n_lights == 0) return 0.0f;
+    Ray r{origin, v, 0.0f};
+    if ((EXT & EXT_CHAIN) && f2i(sc.lights[0].x) == 253) {
+        uint32_t at[4], end[4];
+        float weight[4], sum[4];
+        int sp = 0;
+        at[0] = (uint32_t)f2i(sc.lights[0].y); end[0] = at[0] + (uint32_t)f2i(sc.lights[0].z);
+        weight[0] = 1.0f / (float)f2i(sc.lights[0].z); sum[0] = 0.0f;
+        for (;;) {
+            if (at[sp] == end[sp]) {
+                if (sp == 0) return sum[0];
+                const float inner = sum[sp];
+                --sp;
+                sum[sp] = sum[sp] + weight[sp] * inner;
+                continue;
+            }
+            const uint32_t i = at[sp]++;
+            const float4 a = sc.lights[2 * i], b = sc.lights[2 * i + 1];
+            if (f2i(a.x) == 254 && sp < 3) {
+                ++sp;
+                at[sp] = (uint32_t)f2i(a.y); end[sp] = at[sp] + (uint32_t)f2i(a.z);
+                weight[sp] = 1.0f / (float)f2i(a.z); sum[sp] = 0.0f;
+                continue;
+            }
+            sum[sp] = sum[sp] + weight[sp] * light_pdf_one<STATS, EXT>(a, b, r, origin, v, cnt);
+        }
+    }
+    // The plain list.  The loop body is light_pdf_one() spelled out: as a call to it (force-inlined, or a lambda) the compiler
+    // schedules the shade kernel differently and C3 loses 2 % (profiles/r2/ab_lights_loop_form.txt).
     float weight = 1.0f / (float)sc.n_lights;
     float sum = 0.0f;
-    Ray r{origin, v, 0.0f};
     for (uint32_t i = 0; i < sc.n_lights; ++i) {
         float4 a = sc.lights[2 * i], b = sc.lights[2 * i + 1];
         int type = f2i(a.x);
         float val = 0.0f;
         if (STATS) cnt.light_pdf_evals += 1;
-        if (type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE) {  // sphere.rs:91-105; :204-219: a MovingSphere where it is at time 0
+        if (type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE) {
             float t;
             V3 c = v3(a.y, a.z, a.w);
             if (sphere_roots(c, b.x, r, 0.001f, RT_F32_MAX, &t)) {
@@ -1295,7 +1368,9 @@ RT_DEV float lights_pdf_value(const DScene &sc, V3 origin, V3 v, Counters &cnt) 
                 float solid_angle = 2.0f * 3.14159265358979323846f * (1.0f - cos_theta_max);
                 val = 1.0f / solid_angle;
             }
-        } else if (type != 255) {  // rectangles.rs:54-67
+        } else if ((EXT & EXT_QUADRICS) && type == RT_PRIM_CYLINDER) {
+            val = light_pdf_one<false, EXT>(a, b, r, origin, v, cnt);
+        } else if (type != 255) {
             float t, pa, pb;
             float4 q0 = make_float4(a.y, a.z, a.w, b.x);
             if (rect_test(type, q0, b.y, r, 0.001f, RT_F32_MAX, &t, &pa, &pb)) {
@@ -1495,10 +1570,18 @@ RT_DEV bool shade_material(const DScene &sc, Path &ps, const Rec &rec, float4 ma
         RG_BEGIN(RG_L_LIGHTS);
         if (rts::random_real(rng) < 0.5f) {     // lights.random(rec.p): hittable_list.rs:71-75 then the object's random()
             lobe = 2;
-            const int idx = rts::random_int(rng, 0, (int)sc.n_lights - 1);
+            int idx;
+            if ((EXT & EXT_CHAIN) && f2i(sc.lights[0].x) == 253) {   // lists in the list: every level draws its member
+                idx = 0;
+                do idx = f2i(sc.lights[2 * idx].y) + rts::random_int(rng, 0, f2i(sc.lights[2 * idx].z) - 1);
+                while (f2i(sc.lights[2 * idx].x) == 254);
+            } else
+                idx = rts::random_int(rng, 0, (int)sc.n_lights - 1);
             const float4 la = sc.lights[2 * idx], lb = sc.lights[2 * idx + 1];
             const int type = f2i(la.x);
-            if (type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE) {   // :221-226 for a MovingSphere, whose target is center(time1) - center(time0) (sic)
+            // :221-226 for a MovingSphere, whose target is center(time1) - center(time0) (sic); cylinder.rs:152-161 for a
+            // Cylinder: a sphere of its radius around the centre of its box
+            if (type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE || ((EXT & EXT_QUADRICS) && type == RT_PRIM_CYLINDER)) {
                 const V3 direction = (type == RT_PRIM_SPHERE ? v3(la.y, la.z, la.w) : v3(lb.y, lb.z, lb.w)) - rec.p;
                 distance_squared = length_squared(direction);
                 basis = onb_from(direction);
@@ -1526,7 +1609,7 @@ RT_DEV bool shade_material(const DScene &sc, Path &ps, const Rec &rec, float4 ma
         RG_END(RG_L_COSINE);
         // MixturePdf::value (pdf.rs:68-70)
         RG_BEGIN(RG_L_PDF);
-        float light_val = lights_pdf_value<STATS>(sc, rec.p, dir, cnt);
+        float light_val = lights_pdf_value<STATS, EXT>(sc, rec.p, dir, cnt);
         RG_END(RG_L_PDF);
         float cosine = dot(normalize(dir), uvw.w);
         float cos_val = cosine <= 0.0f ? 0.0f : cosine * (float)0.318309886183790671537767526745028724;

@@ -469,3 +469,93 @@ def test_moving_sphere_in_lights(rt, gpu):
     g_img, c_img, stats = compare_images(rt, gpu, oracle, params, camera, sampler)
     assert stats["light_pdf_evals"] > 0 and np.nanmax(g_img[..., :3]) > 1.0
     assert np.array_equal(np.isnan(g_img), np.isnan(c_img))
+
+
+def cylinder_light_scene(rt):
+    s = rt.host.Scene()
+    grey, red = s.lambertian(s.solid(0.7, 0.7, 0.7)), s.lambertian(s.solid(0.7, 0.2, 0.2))
+    lamp, dark = s.diffuse_light(s.solid(7, 6, 5)), s.diffuse_light(s.solid(0, 0, 0))
+    two_pi = float(np.float32(np.pi) * np.float32(2.0))
+    m = np.eye(4, dtype=np.float32); m[:3, 3] = (3.0, 1.0, -2.0)
+    world = [s.xz_rect(-20, 20, -20, 20, -1.5, grey), s.sphere((-2.5, -0.5, 0), 1, red), s.block((1.5, -1.5, -1), (3.0, 0.0, 0.5), grey),
+             s.cylinder(0.5, -1.0, 1.0, two_pi, lamp),                              # a tube light along z through the origin
+             s.transform(s.cylinder(0.3, -0.5, 0.5, 4.0, lamp), m)]                 # a partial one, moved
+    lights = [s.cylinder(0.5, -1.0, 1.0, two_pi, dark),
+              s.transform(s.cylinder(0.3, -0.5, 0.5, 4.0, dark), m),                # forwarded untransformed (transform.rs:206-212)
+              s.xz_rect(-1, 1, -1, 1, 6, dark)]
+    s.set_roots(s.hittable_list(world), s.hittable_list(lights))
+    return s
+
+
+def test_cylinder_in_lights(rt, gpu):
+    """Cylinder is the one quadric with its own pdf_value / random (cylinder.rs:134-161): the pdf from its hit() and area(),
+    the direction like a sphere of its radius around the centre of its box.  Pinned by hand for one ray, then images and
+    per-pixel ray counts against the oracle."""
+    s = cylinder_light_scene(rt)
+    flat = s.flatten()
+    assert flat.desc.n_lights == 3
+    rec = np.ctypeslib.as_array(flat.desc.lights, (3 * 8,)).copy().reshape(3, 8)
+    two_pi = np.float32(np.pi) * np.float32(2.0)
+    assert rec[0, :1].view(np.int32)[0] == 6                                        # RT_PRIM_CYLINDER
+    assert np.array_equal(rec[0, 1:], np.array([-1.0, 1.0, two_pi, 0.5, 0.0, 0.0, 0.0], np.float32))
+    assert np.array_equal(rec[1, 1:], np.array([-0.5, 0.5, 4.0, 0.3, 0.0, 0.0, 0.0], np.float32))
+    oracle = O.OracleScene(s)
+    # straight down from (0, 3, 0) onto the tube: p = (0, 0.5, 0), |n . -v| = 1, d^2 = 6.25, area = 2 * 0.5 * 2 pi; and onto the
+    # partial one where it is WITHOUT its Transform: p = (0, 0.3, 0) at phi = pi / 2 < 4, d^2 = 7.29, area = 1 * 0.3 * 4
+    got = oracle.lights_pdf_value(np.array([0, 3, 0], np.float32), np.array([0, -1, 0], np.float32))
+    assert got == pytest.approx((6.25 / (2.0 * np.pi) + 7.29 / 1.2) / 3.0, rel=1e-5)
+    assert oracle.lights_pdf_value(np.array([0, 3, 5], np.float32), np.array([0, -1, 0], np.float32)) == 0.0
+    params = rt.host.RaytracerConfig.load().scene_params("CornellBox").replace(
+        image_width=96, aspect_ratio=1.5, samples_per_pixel=16, look_from=(0.0, 3.0, 11.0), look_at=(0.5, 0.0, 0.0),
+        vertical_fov=40.0, background=(0.02, 0.02, 0.03))
+    camera, sampler = params.camera(), rt.host.MultiJitteredSampler(16)
+    gpu.upload_scene(flat)
+    gpu.upload_sampler(sampler)
+    g_img, c_img, stats = compare_images(rt, gpu, oracle, params, camera, sampler)
+    assert stats["light_pdf_evals"] > 0 and np.nanmax(g_img[..., :3]) > 1.0
+    assert np.array_equal(np.isnan(g_img), np.isnan(c_img))
+
+
+def nested_light_lists_scene(rt):
+    s = rt.host.Scene()
+    grey, red = s.lambertian(s.solid(0.7, 0.7, 0.7)), s.lambertian(s.solid(0.7, 0.2, 0.2))
+    lamp, dark = s.diffuse_light(s.solid(7, 6, 5)), s.diffuse_light(s.solid(0, 0, 0))
+    two_pi = float(np.float32(np.pi) * np.float32(2.0))
+    world = [s.xz_rect(-20, 20, -20, 20, -1.5, grey), s.sphere((-2.5, -0.5, 0), 1, red), s.block((1.5, -1.5, -1), (3.0, 0.0, 0.5), grey),
+             s.cylinder(0.5, -1.0, 1.0, two_pi, lamp), s.flip_face(s.xz_rect(-1, 1, -1, 1, 6, lamp)),
+             s.sphere((4, 2, -1), 0.5, lamp), s.sphere((-4, 3, 1), 0.4, lamp)]
+    inner = s.hittable_list([s.cylinder(0.5, -1.0, 1.0, two_pi, dark), s.xz_rect(-1, 1, -1, 1, 6, dark)])
+    lights = [s.xz_rect(-1, 1, -1, 1, 6, dark),
+              s.hittable_list([s.sphere((4, 2, -1), 0.5, dark), inner]),                       # a list in a list in `lights`
+              s.translate(s.hittable_list([s.sphere((-4, 3, 1), 0.4, dark)]), (9, 9, 9))]       # a wrapped one: forwarded
+    s.set_roots(s.hittable_list(world), s.hittable_list(lights))
+    return s
+
+
+def test_lists_inside_lights(rt, gpu):
+    """HittableList::pdf_value is the mean of its members' pdfs and ::random draws a member (hittable_list.rs:59-75); a list
+    that is itself a member does the same one level down, with a draw of its own.  Layout pinned, then images and per-pixel
+    ray counts against the oracle's nested lists."""
+    s = nested_light_lists_scene(rt)
+    flat = s.flatten()
+    n = flat.desc.n_lights
+    rec = np.ctypeslib.as_array(flat.desc.lights, (n * 8,)).copy().reshape(n, 8)
+    kinds = rec[:, 0].view(np.int32).tolist()
+    runs = rec[:, 1:3].view(np.int32)
+    # root | rect, list, list | sphere, list | sphere | cylinder, rect
+    assert kinds == [253, 3, 254, 254, 0, 254, 0, 6, 3]
+    assert runs[0].tolist() == [1, 3] and runs[2].tolist() == [4, 2] and runs[3].tolist() == [6, 1] and runs[5].tolist() == [7, 2]
+    oracle = O.OracleScene(s)
+    # from (0, 3, 0) straight up: only the two rectangles at y = 6 are hit (d^2 = 9, cosine 1, area 4): 9/4 as a member of
+    # `lights` and as a member of the innermost list: (1/3) (9/4 + (1/2) (0 + (1/2) (0 + 9/4)) + 0)
+    got = oracle.lights_pdf_value(np.array([0, 3, 0], np.float32), np.array([0, 1, 0], np.float32))
+    assert got == pytest.approx((2.25 + 0.25 * 2.25) / 3.0, rel=1e-6)
+    params = rt.host.RaytracerConfig.load().scene_params("CornellBox").replace(
+        image_width=96, aspect_ratio=1.5, samples_per_pixel=16, look_from=(0.0, 3.0, 11.0), look_at=(0.5, 0.0, 0.0),
+        vertical_fov=40.0, background=(0.02, 0.02, 0.03))
+    camera, sampler = params.camera(), rt.host.MultiJitteredSampler(16)
+    gpu.upload_scene(flat)
+    gpu.upload_sampler(sampler)
+    g_img, c_img, stats = compare_images(rt, gpu, oracle, params, camera, sampler)
+    assert stats["light_pdf_evals"] > 0 and np.nanmax(g_img[..., :3]) > 1.0
+    assert np.array_equal(np.isnan(g_img), np.isnan(c_img))

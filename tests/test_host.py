@@ -574,3 +574,41 @@ def test_c5_workload_is_the_4k_frame_split_over_eight_ranks(rt):
     assert (name, params.image_width, params.image_height, params.samples_per_pixel) == ("Chapter2Final", 3840, 2160, 16384)
     ranges = [rt.sharding.sample_range(r, 8, params.samples_per_pixel) for r in range(8)]
     assert ranges == [(2048 * r, 2048) for r in range(8)]
+
+
+def test_lights_records_for_cylinders_and_nested_lists(rt):
+    """`lights` entries beyond spheres and rectangles (rt_api.h "light"): a Cylinder (cylinder.rs:134-161) and lists inside the
+    list (hittable_list.rs:59-75), laid out behind a root record run by run; the oracle's nested lists give the hand-computed pdf."""
+    import oracle_ffi as O
+    s = rt.host.Scene()
+    dark = s.diffuse_light(s.solid(0, 0, 0))
+    two_pi = float(np.float32(np.pi) * np.float32(2.0))
+    world = s.hittable_list([s.sphere((0, -100, 0), 1, dark)])
+    s.set_roots(world, s.hittable_list([s.cylinder(0.5, 1.0, -1.0, two_pi, dark), s.xz_rect(-1, 1, -1, 1, 6, dark)]))
+    f = s.flatten()
+    rec = np.ctypeslib.as_array(f.desc.lights, (2 * 8,)).copy().reshape(2, 8)
+    assert rec[:, 0].view(np.int32).tolist() == [6, 3]                               # no root record without nested lists
+    assert np.array_equal(rec[0, 1:], np.array([-1.0, 1.0, two_pi, 0.5, 0.0, 0.0, 0.0], np.float32))   # zmin / zmax as Cylinder::new sorts them
+    o = O.OracleScene(s)
+    got = o.lights_pdf_value(np.array([0, 3, 0], np.float32), np.array([0, -1, 0], np.float32))
+    assert got == pytest.approx(0.5 * 6.25 / (2.0 * np.pi), rel=1e-6)                # p = (0, 0.5, 0), d^2 = 6.25, area = 2 * 0.5 * 2 pi
+    inner = s.hittable_list([s.cylinder(0.5, -1.0, 1.0, two_pi, dark), s.xz_rect(-1, 1, -1, 1, 6, dark)])
+    s.set_roots(world, s.hittable_list([s.xz_rect(-1, 1, -1, 1, 6, dark), s.hittable_list([s.sphere((4, 2, -1), 0.5, dark), inner]),
+                                        s.translate(s.hittable_list([s.sphere((-4, 3, 1), 0.4, dark)]), (9, 9, 9))]))
+    f = s.flatten()
+    n = f.desc.n_lights
+    rec = np.ctypeslib.as_array(f.desc.lights, (n * 8,)).copy().reshape(n, 8)
+    assert rec[:, 0].view(np.int32).tolist() == [253, 3, 254, 254, 0, 254, 0, 6, 3]  # root | rect, list, list | sphere, list | sphere | cylinder, rect
+    runs = rec[:, 1:3].view(np.int32)
+    assert [runs[k].tolist() for k in (0, 2, 3, 5)] == [[1, 3], [4, 2], [6, 1], [7, 2]]
+    got = O.OracleScene(s).lights_pdf_value(np.array([0, 3, 0], np.float32), np.array([0, 1, 0], np.float32))
+    assert got == pytest.approx((2.25 + 0.25 * 2.25) / 3.0, rel=1e-6)                # the rectangle at y = 6, as a member of two lists
+    s.set_roots(world, s.hittable_list([s.hittable_list([])]))
+    with pytest.raises(rt.RtError):                                                  # random() would index objects[random_int(0, -1)]
+        s.flatten()
+    deep = s.sphere((0, 5, 0), 1, dark)
+    for _ in range(5):
+        deep = s.hittable_list([deep])
+    s.set_roots(world, deep)
+    with pytest.raises(rt.RtError):                                                  # at most 4 lists deep
+        s.flatten()
