@@ -136,6 +136,59 @@ def test_a_cyclic_tree_or_an_under_declared_stack_is_found_on_the_host(rt, ctx):
     assert np.array_equal(again.view(np.uint32), ref.view(np.uint32))
 
 
+def test_bad_chain_and_light_list_records_are_refused(rt, ctx):
+    """Chain records (xform flags 8) and the list records of `lights` (253 / 254) are indices the kernels follow: a run outside
+    its array, a chain inside a chain, a list that points at or before itself (a cycle) or a record that no list owns are all
+    found by rt_scene_upload."""
+    b, flat0, params, camera, sampler = ctx
+    s = rt.host.Scene()
+    m, dark = s.lambertian(s.solid(0.5, 0.5, 0.5)), s.diffuse_light(s.solid(0, 0, 0))
+    world = [s.rotate_y(s.translate(s.sphere((0, 0, 0), 1, m), (1, 0, 0)), 30.0), s.xz_rect(-5, 5, -5, 5, -1, m)]
+    lights = [s.xz_rect(-1, 1, -1, 1, 6, dark), s.hittable_list([s.sphere((4, 2, -1), 0.5, dark), s.sphere((0, 3, 0), 0.5, dark)])]
+    s.set_roots(s.hittable_list(world), s.hittable_list(lights))
+    flat = s.flatten()
+    d0 = flat.desc
+    assert b._L.rt_scene_upload(b._h, C.byref(d0)) == 0
+    x = np.ctypeslib.as_array(d0.xforms, shape=(int(d0.n_xforms) * 8,)).copy().view(np.int32).reshape(-1, 8)
+    chain = int(np.nonzero(x[:, 0] == 8)[0][0])
+    li = np.ctypeslib.as_array(d0.lights, shape=(int(d0.n_lights) * 8,)).copy().view(np.int32).reshape(-1, 8)
+    assert li[:, 0].tolist() == [253, 3, 254, 0, 0]
+    keep = []
+
+    def xf(row, word, value):
+        a = x.copy(); a[row, word] = value; keep.append(a)
+        d = copy_of(d0); d.xforms = a.view(np.float32).ctypes.data_as(rt._ffi.c_float_p)
+        return d
+
+    def lt(row, word, value, n=None):
+        a = li.copy(); a[row, word] = value; keep.append(a)
+        d = copy_of(d0); d.lights = a.view(np.float32).ctypes.data_as(rt._ffi.c_float_p)
+        if n is not None:
+            d.n_lights = n
+        return d
+
+    cases = [
+        (xf(chain, 2, 9), RT_E_INVALID, "xform chain"),                    # more than 8 records
+        (xf(chain, 2, int(d0.n_xforms)), RT_E_INVALID, "xform chain"),     # (would also run past the array)
+        (xf(chain, 1, -1), RT_E_INVALID, "xform chain"),
+        (xf(int(x[chain, 1]), 0, 8), RT_E_INVALID, "not a plain record"),  # a chain inside a chain
+        (lt(0, 2, 9), RT_E_INVALID, "root record"),                        # the root's run past the array
+        (lt(0, 1, 0), RT_E_INVALID, "root record"),                        # ... or starting at itself
+        (lt(2, 1, 2), RT_E_INVALID, "bad list record"),                    # a list that is its own member
+        (lt(2, 1, 1), RT_E_INVALID, "bad list record"),                    # members before the record: a cycle
+        (lt(2, 2, 1), RT_E_INVALID, "belongs to no list"),                 # the second sphere is nobody's member now
+        (lt(1, 0, 254), RT_E_INVALID, "bad list record"),                  # a list record whose words are no run (a rectangle's floats)
+        (lt(0, 0, 253, n=2), RT_E_INVALID, "root record"),                 # fewer records than the root's run
+        (lt(0, 0, 254), RT_E_UNSUPPORTED_PRIMITIVE, "light 0: type 254"),  # list records need the root record
+        (lt(1, 0, 9), RT_E_UNSUPPORTED_PRIMITIVE, "light 1: type 9"),
+    ]
+    for d, want, text in cases:
+        st, msg = status_and_text(b, b._L.rt_scene_upload(b._h, C.byref(d)))
+        assert st == want and text in msg, (st, msg, text)
+    b.upload_scene(flat0)                                                  # the module's scene back in place
+    b.upload_sampler(sampler)
+
+
 def test_bad_sampler_tables_are_refused(rt, ctx):
     b, flat, params, camera, sampler = ctx
     d = copy_of(sampler.desc)
