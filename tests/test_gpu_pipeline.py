@@ -75,6 +75,7 @@ def test_reference_image_matches_the_oracle(rt, gpu, book2):
     {"RT_WF_TILE_STRIDE": 1, "RT_WF_SAMPLE_MAJOR": 0},   # items handed out tile by tile in raster order (default: sample-major along a golden-section stride)
     {"RT_WF_TILE_STRIDE": 7},
     {"RT_WF_SAMPLE_MAJOR": 0, "RT_WF_PIPES": 3, "RT_WF_POOL_LOG2": 15},
+    {"RT_KERNEL_SET": "full"},                     # the kernels instantiated with quadrics and general Transforms too (default: the smallest set that covers the scene)
 ])
 def test_image_is_independent_of_the_pipeline_geometry(gpu, book2, env):
     scene, params, camera, sampler, ref = book2
