@@ -769,7 +769,29 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         UP(materials, dev_mats.data(), dev_mats.size() * 4);
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // dev_mats goes out of scope
     }
-    UP(textures, s->textures, (size_t)s->n_textures * RT_REC_FLOATS * 4);
+    {   // device copy of the textures: a checker whose two branches are solid colours (the ground of C1, the spheres of
+        // TwoSpheres) becomes one record of kind RT_TEX_CHECKER_SOLIDS holding both colours, so that its lookup is one
+        // fetch instead of a checker record followed by a dependent fetch of the branch taken (rt_kernels.h texture_value)
+        std::vector<float> dev_tex(s->textures, s->textures + (size_t)s->n_textures * RT_REC_FLOATS);
+        for (uint32_t i = 0; i < s->n_textures; ++i) {
+            int32_t w[8];
+            memcpy(w, &s->textures[(size_t)i * RT_REC_FLOATS], 32);
+            if (w[0] != RTG_TEX_CHECKER) continue;
+            const float *odd = &s->textures[(size_t)w[4] * RT_REC_FLOATS], *even = &s->textures[(size_t)w[5] * RT_REC_FLOATS];
+            int32_t ko, ke;
+            memcpy(&ko, odd, 4); memcpy(&ke, even, 4);
+            if (ko != RTG_TEX_SOLID || ke != RTG_TEX_SOLID) continue;
+            float *t = &dev_tex[(size_t)i * RT_REC_FLOATS];
+            const int32_t kind = RT_TEX_CHECKER_SOLIDS;
+            const float scale = s->textures[(size_t)i * RT_REC_FLOATS + 6];
+            memcpy(t, &kind, 4);
+            memcpy(t + 1, odd + 1, 12);
+            memcpy(t + 4, even + 1, 12);
+            t[7] = scale;
+        }
+        UP(textures, dev_tex.data(), dev_tex.size() * 4);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // dev_tex goes out of scope
+    }
     UP(perlin, s->perlin, (size_t)s->n_perlin * RT_PERLIN_WORDS * 4);
     UP(texels, s->texels, (size_t)s->n_texel_bytes);
     UP(moving, s->moving_slots, (size_t)s->n_moving_slots * 4);

@@ -1196,6 +1196,9 @@ RT_DEV float coop_turbulence(const DScene &sc, unsigned long long m_need, V3 p, 
     return out;
 }
 
+// Device-only texture kind (rt_scene_upload writes it into its copy of the texture records; never in an rt_scene_desc)
+enum { RT_TEX_CHECKER_SOLIDS = 4 };
+
 template <int EXT = EXT_ALL>
 RT_DEV bool texture_needs_uv(const DScene &sc, int tex) {
     if (!(EXT & EXT_IMAGE)) return false;     // u, v only matter to an image texture
@@ -1220,6 +1223,12 @@ RT_DEV V3 texture_value(const DScene &sc, int tex, float u, float v, V3 p, Count
         int type = f2i(a.x);
         if (STATS) cnt.tex_evals[type & 3] += 1;
         if (type == RTG_TEX_SOLID) return v3(a.y, a.z, a.w);
+        if (type == RT_TEX_CHECKER_SOLIDS) {  // device copy of a checker over two solid colours: odd rgb | even rgb, scale
+            if (STATS) cnt.tex_evals[RTG_TEX_CHECKER] += 1;   // (the line above has counted the solid colour: type & 3 == 0)
+            float f = b.w;
+            float sines = pm::sinf_(f * p.x) * pm::sinf_(f * p.y) * pm::sinf_(f * p.z);
+            return sines < 0.0f ? v3(a.y, a.z, a.w) : v3(b.x, b.y, b.z);
+        }
         if (type == RTG_TEX_CHECKER) {  // checker_texture.rs:37-45
             float f = b.z;
             float sines = pm::sinf_(f * p.x) * pm::sinf_(f * p.y) * pm::sinf_(f * p.z);
