@@ -559,3 +559,32 @@ def test_lists_inside_lights(rt, gpu):
     g_img, c_img, stats = compare_images(rt, gpu, oracle, params, camera, sampler)
     assert stats["light_pdf_evals"] > 0 and np.nanmax(g_img[..., :3]) > 1.0
     assert np.array_equal(np.isnan(g_img), np.isnan(c_img))
+
+
+def test_checkers_of_every_shape(rt, gpu):
+    """rt_scene_upload folds a checker over two solid colours into one device record; every other checker (a branch that is
+    a checker, a noise texture or an image) keeps the two-level form, and one of those may point at a folded one.  Tex-eval
+    counters, ray counts and images against the oracle (checker_texture.rs:37-45)."""
+    s = rt.host.Scene()
+    plain = s.checker(s.solid(0.2, 0.3, 0.1), s.solid(0.9, 0.85, 0.8), 10.0)                  # folded
+    nested = s.checker(plain, s.solid(0.7, 0.2, 0.2), 1.5)                                    # a folded checker inside a checker
+    twice = s.checker(nested, s.checker(s.solid(0.1, 0.1, 0.6), s.solid(0.6, 0.6, 0.1), 6.0), 0.7)
+    marbled = s.checker(s.noise(4.0), s.solid(0.8, 0.8, 0.8), 3.0)                            # a branch that is Perlin noise
+    rgba = np.zeros((8, 8, 4), np.uint8); rgba[..., 0] = np.arange(8)[None, :] * 30; rgba[..., 1] = np.arange(8)[:, None] * 30; rgba[..., 3] = 255
+    pictured = s.checker(s.image(rgba), s.solid(0.3, 0.3, 0.3), 5.0)                          # a branch that reads u, v
+    world = [s.xz_rect(-30, 30, -30, 30, 0, s.lambertian(twice)), s.sphere((-3.2, 1, 0), 1, s.lambertian(plain)),
+             s.sphere((-1, 1, 0.5), 1, s.lambertian(nested)), s.sphere((1.2, 1, 0), 1, s.lambertian(marbled)),
+             s.sphere((3.4, 1, 0.5), 1, s.lambertian(pictured)), s.sphere((0, 1, -3), 1, s.diffuse_light(plain)),
+             s.flip_face(s.xz_rect(-2, 2, -2, 2, 6, s.diffuse_light(s.solid(6, 6, 6))))]
+    s.set_roots(s.hittable_list(world), s.hittable_list([s.xz_rect(-2, 2, -2, 2, 6, s.diffuse_light(s.solid(0, 0, 0)))]))
+    params = rt.host.RaytracerConfig.load().scene_params("CornellBox").replace(
+        image_width=128, aspect_ratio=1.6, samples_per_pixel=16, look_from=(0.0, 4.0, 11.0), look_at=(0.0, 1.0, 0.0),
+        vertical_fov=40.0, background=(0.25, 0.35, 0.55))
+    camera, sampler = params.camera(), rt.host.MultiJitteredSampler(16)
+    gpu.upload_scene(s.flatten())
+    gpu.upload_sampler(sampler)
+    oracle = O.OracleScene(s)
+    g_img, c_img, stats = compare_images(rt, gpu, oracle, params, camera, sampler)
+    assert np.isfinite(g_img).all()
+    ev = stats["tex_evals"]
+    assert ev[1] > ev[0] * 0.5 and ev[2] > 0 and ev[3] > 0      # checkers (several levels per hit), noise and image branches were all taken
