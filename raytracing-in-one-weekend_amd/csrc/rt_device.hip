@@ -555,6 +555,9 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     if (s->n_slots && !s->slots) return fail(ctx, RT_E_INVALID, "slots missing");
     if (s->n_bvh_nodes && !s->bvh_nodes) return fail(ctx, RT_E_INVALID, "bvh_nodes missing");
     if (s->n_media > RT_MAX_MEDIA) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "at most %d ConstantMedium objects are supported", RT_MAX_MEDIA);
+    if ((s->n_xforms && !s->xforms) || (s->n_media && !s->media) || (s->n_lights && !s->lights) || (s->n_materials && !s->materials) ||
+        (s->n_textures && !s->textures))
+        return fail(ctx, RT_E_INVALID, "a record array (xforms / media / lights / materials / textures) is missing");
     if (s->n_lights == 0) return fail(ctx, RT_E_INVALID, "`lights` is empty (the reference indexes objects[random_int(0,-1)], hittable_list.rs:71-75)");
     if ((uint64_t)s->always_begin + s->always_count > s->n_slots) return fail(ctx, RT_E_INVALID, "always-list outside the slot array");
     if (s->n_slots >= (1u << 28)) return fail(ctx, RT_E_INVALID, "too many primitives");

@@ -82,6 +82,9 @@ def test_bad_scene_descriptors_are_refused_and_the_old_scene_stays(rt, ctx):
         (field(bvh_stack_depth=0), RT_E_INVALID, "bvh_stack_depth"),
         (field(n_media=5), RT_E_UNSUPPORTED_PRIMITIVE, "ConstantMedium"),
         (field(slots=None), RT_E_INVALID, "slots missing"),
+        (field(lights=None), RT_E_INVALID, "record array"),
+        (field(materials=None), RT_E_INVALID, "record array"),
+        (field(textures=None), RT_E_INVALID, "record array"),
         (with_slot_word(n - 1, 5, int(flat.desc.n_materials)), RT_E_INVALID, "material out of range"),
         (with_slot_word(0, 5, -1), RT_E_INVALID, "material out of range"),
         (with_slot_word(n // 2, 4, 15), RT_E_UNSUPPORTED_PRIMITIVE, "primitive type"),
