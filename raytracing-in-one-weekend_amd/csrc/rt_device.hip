@@ -313,6 +313,8 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     const unsigned tail_blk = tail_blk_env >= 256 ? 256u : tail_blk_env >= 128 ? 128u : 64u;   // threads per workgroup (its waves are independent)
     const size_t tail_lds = (size_t)lds_depth * tail_blk * sizeof(StackEntry);
     const int tail_group = (int)env_size("RT_WF_TAIL_GROUP", 2, 1, 16);   // iterations enqueued at a time once every item is out
+    const uint32_t tail_regroup = (uint32_t)env_size("RT_WF_TAIL_REGROUP", 1, 0, 1);   // survivors of a tail iteration are grouped by the slot they last hit
+    const uint32_t tail_hint = (uint32_t)env_size("RT_WF_TAIL_HINT", 1, 0, 1);         // a bounce's walk starts with the sphere the path has just hit as a candidate
 
     struct Pipe {
         hipStream_t s;
@@ -400,7 +402,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                                ctx->wf_samples, d_stats, d_rays, with_tail);
             if (with_tail)
                 hipLaunchKernelGGL(tail_kernel, dim3(tail_waves * 64u / tail_blk), dim3(tail_blk), tail_lds, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
-                                   tail_bounces, tail_bounces2, tail_set, tail_thin, lds_depth, P.ovf, ctx->wf_samples, d_stats, d_rays);
+                                   tail_bounces, tail_bounces2, tail_set, tail_thin, lds_depth, P.ovf, ctx->wf_samples, d_stats, d_rays, tail_regroup, tail_hint);
             hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, nxt, P.ctr, it,
                                ctx->wf_samples, P.d_status, d_stats, d_rays);
         };
@@ -434,13 +436,17 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                         P.chunks = need < 1u ? 1u : (need < P.w.cap / 256u ? need : P.w.cap / 256u);
                         const unsigned tb = P.chunks * RT_WF_SHARDS;
                         P.trav_blocks = tb < trav_blocks ? tb : trav_blocks;
-                        if (tail_max && hs[0] <= tail_max) {   // tail mode (the pool only shrinks): every iteration from here takes tail_bounces
-                            // units of depth off every path, so this many more iterations empty the pool whatever the scene
+                        if (tail_max && hs[0] <= tail_max) {   // tail mode (the pool only shrinks): every iteration enqueued from here on is
+                            // a tail iteration; the first of them takes at least min(tail_bounces, tail_bounces2) units of depth off
+                            // every path (it may be the first tail iteration or a later one), each one after it tail_bounces2: that
+                            // many more iterations empty the pool whatever the scene (Book-1 at depth 50: 4 + 64 bounces = 2)
                             const uint32_t depth = (uint32_t)(a.max_depth > 0 ? a.max_depth : 0);
-                            const uint32_t per_it = tail_bounces < tail_bounces2 ? tail_bounces : tail_bounces2;
-                            const uint32_t end = P.it + (depth + per_it - 1u) / per_it + 1u;
+                            const uint32_t first = tail_bounces < tail_bounces2 ? tail_bounces : tail_bounces2;
+                            const uint32_t end = P.it + 1u + (depth > first ? (depth - first + tail_bounces2 - 1u) / tail_bounces2 : 0u);
                             if (end < P.it_end) P.it_end = end;
                         }
+                        // (belt and braces: everything enqueued has run and something is still alive — go on one iteration at a time)
+                        if (hs[2] == P.it + 1u && P.it >= P.it_end) P.it_end = P.it + 1u;
                     }
                 }
                 if (group >= 1)      // (group 0 was enqueued above)

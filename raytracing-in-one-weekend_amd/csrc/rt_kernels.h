@@ -1093,6 +1093,25 @@ RT_DEV void trav_leaf_test(const DScene &sc, const Ray &r, float t_min, Trav &tv
     }
 }
 
+// A candidate ahead of the walk: the slot `slot` (one the walk can reach: a BVH leaf), if it is a plain sphere.  Its test is the
+// leaf's own (sphere.rs:45-66 with the walk's bounds), so an accepted hit is what the walk would fold when it meets the leaf — if
+// it meets it: the walk only tests a leaf whose box the ray passes through, and in f32 a sphere can accept a ray that passes far
+// from it (cancellation), so the hit only counts when its point lies on the sphere to within half the padding of
+// the boxes, i.e. inside every box above the leaf.  The fold does not depend on the order candidates arrive in, and the walk
+// leaves the slot as it is when it meets it again (same t, same id).
+RT_DEV void hint_sphere(const DScene &sc, uint32_t slot, const Ray &r, float t_min, Trav &tv) {
+    const SlotRec s = load_slot(sc, slot);
+    const int w4 = f2i(s.meta.x);
+    if ((w4 & 15) != RT_PRIM_SPHERE || (w4 >> 8) != 0) return;
+    const V3 c = v3(s.q0.x, s.q0.y, s.q0.z);
+    float t;
+    if (!sphere_roots(c, s.q0.w, r, t_min, tv.best.t, &t)) return;
+    const float r2 = s.q0.w * s.q0.w;
+    if (!(fabsf(length_squared(r.at(t) - c) - r2) <= 1.0e-4f * r2)) return;
+    const int32_t id = f2i(s.meta.z);
+    if (id > tv.floor_id) consider(tv.best, t, id, (int32_t)slot);
+}
+
 // After the walk: if nothing came after the last NaN candidate, that candidate is the hit.
 template <bool STATS, int EXT = EXT_ALL>
 RT_DEV void finish_trace(const DScene &sc, const Ray &r, float t_min, float t_max, Trav &tv, Counters &cnt) {

@@ -121,6 +121,35 @@ RT_DEV uint32_t wave_append(uint32_t *counter, bool keep) {
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// wave_append() with a shard of its own per lane: the lanes with `keep` are appended to the shards `target` names (one atomic per
+// distinct shard among them).  A shard that is full passes what does not fit on to the next one (and takes the overshoot off its
+// counter again, so a counter ends at the number of entries placed: once a counter has passed `cap` every position below `cap` is
+// taken, so nobody is handed one of those twice).  Ends because the pool holds every live path.  Returns the pool index.
+RT_DEV uint32_t wave_append_to(WfCounters *c, uint32_t cap, bool keep, uint32_t target) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t pos = 0;
+    unsigned long long todo = __ballot(keep);
+    while (todo != 0ull) {      // wave-uniform
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)target, leader);
+        const bool mine = keep && ((todo >> lane) & 1ull) != 0ull && target == s;
+        const unsigned long long m = __ballot(mine);
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        uint32_t base = 0;
+        if ((int)lane == leader) {
+            base = atomicAdd(&c->sh[s].n_surv, cnt);
+            if (base + cnt > cap) atomicSub(&c->sh[s].n_surv, base >= cap ? cnt : base + cnt - cap);
+        }
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const bool placed = mine && at < cap;
+        if (placed) pos = s * cap + at;
+        if (mine && !placed) target = (s + 1u) % RT_WF_SHARDS;
+        todo &= ~__ballot(placed);
+    }
+    return pos;
+}
+
 template <bool STATS>
 RT_DEV void flush_counters(const Counters &cnt, uint32_t paths, unsigned long long *stats) {
     if (kTimers && !STATS) {
@@ -513,7 +542,7 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
 template <bool STATS, int EXT>
 __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ q, PathQ nxt, WfCounters *ctr, uint32_t it, uint32_t first_bounces,
                                                      uint32_t later_bounces, uint32_t set_lanes_max, uint32_t thin_below, uint32_t lds_depth, StackEntry *ovf, float4 *__restrict__ samples,
-                                                     unsigned long long *stats, uint32_t *pixel_rays) {
+                                                     unsigned long long *stats, uint32_t *pixel_rays, uint32_t regroup, uint32_t hint) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wpb = blockDim.x >> 6;
     const uint32_t gw = blockIdx.x * wpb + (threadIdx.x >> 6), n_gw = gridDim.x * wpb;   // this wave among all waves of the launch
@@ -541,6 +570,7 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
         if (lane >= o) sets_incl += up;
     }
     const uint32_t n_sets = (uint32_t)__shfl((int)sets_incl, 63, 64);
+    if (blockIdx.x * wpb >= n_sets) return;             // block-uniform: no set for any wave of this workgroup
     const Stack stack{(LdsStackPtr)lds_stack + threadIdx.x, blockDim.x, lds_depth, ovf ? ovf + (size_t)blockIdx.x * blockDim.x + threadIdx.x : nullptr, gridDim.x * blockDim.x};
     const V3 background = v3(w.a.bg[0], w.a.bg[1], w.a.bg[2]);
     const float T_MIN = 0.001f;
@@ -552,6 +582,7 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
         const uint32_t n = (uint32_t)__shfl((int)my_count, (int)shard, 64), off = (set - first_set) * set_lanes;
         const uint32_t i = shard * w.cap + off + lane;
         bool alive = false, walk = false;
+        uint32_t where = 0xffffffffu;      // the slot the path's last hit was on, once it has had one in this launch
         WfPath p;
         p.ps.ray.o = v3(0.0f, 0.0f, 0.0f); p.ps.ray.d = p.ps.ray.o; p.ps.ray.time = 0.0f;
         p.ps.throughput = p.ps.ray.o; p.ps.radiance = p.ps.ray.o; p.ps.depth = 0;
@@ -589,6 +620,11 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
             RG_BEGIN(RG_TRAV_ALL);
             {      // the walk, as wf_traverse_kernel does it without the refill: leaves put aside, RT_WF_NODE_STEPS node steps per turn
                 const bool walking = alive && walk;
+                // What lives this long is caught inside something and hits it again and again from within (rt_device.hip, tail
+                // kernel): the slot of the last hit is tested before the walk, so the walk starts with best.t at the far side of
+                // that object instead of infinity and prunes everything beyond it from the first node on.  One more candidate for
+                // the same fold (the walk meets the slot again and leaves it as it is): the same closest hit, the same tie-break.
+                if (hint && walking && where < sc.always_begin) hint_sphere(sc, where, p.ps.ray, T_MIN, tv);
                 int32_t pend = RT_BVH_EMPTY;
                 for (;;) {
 #pragma unroll
@@ -620,6 +656,7 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
             bool survive = false;
             RG_BEGIN(RG_SHADE_ALL);
             if (alive) finish_trace<STATS, EXT>(sc, p.ps.ray, T_MIN, INFINITY, tv, cnt);
+            if (alive && tv.best.id >= 0) where = (uint32_t)tv.best.slot;
             const bool cont = shade_hit<STATS, EXT>(sc, alive, p.ps, tv.best, background, p.rng, cnt);
             if (alive) {
                 survive = cont && p.ps.depth > 0;
@@ -638,8 +675,13 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
             }
             RG_END(RG_BEGIN_ALL);
         }
-        // what is still alive goes on in the next iteration: appended to the set's own shard of the next buffer (as shade does)
-        const uint32_t pos = shard * w.cap + wave_append(&c->sh[shard].n_surv, alive);
+        // What is still alive goes on in the next iteration.  Regrouped: appended to the shard its last hit's slot names, so that the
+        // next iteration's sets — consecutive entries of a shard — hold paths that are in the same place.  What lives this long
+        // is caught somewhere (the Book-1 frame: nine of ten are reflected to and fro inside the big metal sphere, the rest
+        // inside a handful of others), so such a set walks the same nodes and runs one branch of the material switch, bounce
+        // after bounce.  Where an entry sits changes no bit: its sample is parked by item index.  Otherwise: to the set's own
+        // shard, as shade does.
+        const uint32_t pos = regroup ? wave_append_to(c, w.cap, alive, (where == 0xffffffffu ? shard : where) % RT_WF_SHARDS) : shard * w.cap + wave_append(&c->sh[shard].n_surv, alive);
         if (alive) store_entry(nxt, pos, p, tv, walk);
     }
     if (kTimers && !STATS) {   // development builds: the kernel's own timers apart from the pipeline's (stats + 64)
