@@ -41,7 +41,8 @@ F_SHADE = [140, 45, 60, 2, 20]      # lambertian+mixture pdf, metal, dielectric,
 F_TEX = [0, 8, 1000, 12]            # solid, checker, noise (7 octaves), image
 F_CAMERA = 40
 PEAK_FP32_VALU_TFLOPS = 157.3       # MI355X_MICROARCH.md "Peak FP32 (vector)"
-PROFILE_ROUND = "r2"
+PROFILE_ROUND = "r3"
+KERNELS = ("generate", "traverse", "shade", "tail")
 
 # sub-workloads of the default run: (name, timed steps, warm-up steps).  C3's frame is 6.4e9 paths: one timed step.
 SUB_WORKLOADS = (("C2", 3, 1), ("C3", 1, 0), ("C4", 3, 1))
@@ -56,6 +57,29 @@ def algorithmic_flops(st):
     f += sum(n * c for n, c in zip(st["shades"], F_SHADE)) + sum(n * c for n, c in zip(st["tex_evals"], F_TEX))
     f += st["light_pdf_evals"] * 30 + st["paths"] * F_CAMERA
     return f
+
+
+def kernel_busy_ms(name, base_spp):
+    """Busy time per frame of every render kernel, from the committed rocprofv3 --kernel-trace --stats summary of this workload
+    (profiles/<round>/<wl>_<spp>spp_kernel_stats.csv: the product kernels are the `<false, ...>` instantiations, the traced run
+    renders steps + warm-up frames with them, profiles/<round>/<wl>_<spp>spp_ktrace_bench.json says how many)."""
+    import csv
+    base = os.path.join(ROOT, "profiles", PROFILE_ROUND, "%s_%dspp" % (name.lower(), base_spp))
+    if not (os.path.exists(base + "_kernel_stats.csv") and os.path.exists(base + "_ktrace_bench.json")):
+        return None, None
+    with open(base + "_ktrace_bench.json") as f:
+        line = json.loads(f.read().strip().splitlines()[-1])
+    frames = line["steps"] + line["warmup"]
+    busy = {}
+    with open(base + "_kernel_stats.csv") as f:
+        for r in csv.DictReader(f):
+            n = r["Name"]
+            for k in KERNELS + ("fold",):
+                if "rtk::wf_%s_kernel" % k in n and ("<false" in n or k == "fold"):
+                    # (the fold kernel is not a template: its rows hold the counting run's frame too)
+                    per = frames + 1 if k == "fold" else frames
+                    busy[k] = busy.get(k, 0.0) + float(r["TotalDurationNs"]) / 1e6 / per
+    return busy, os.path.relpath(base + "_kernel_stats.csv", ROOT)
 
 
 def spawn_ranks(n):
@@ -187,6 +211,20 @@ class Bench:
             traffic = sum(2.0 * (k.get("fetch_size_kb") or 0.0) + (k.get("write_size_kb") or 0.0) for k in ks) * 1024.0
             traffic_src = os.path.relpath(prof, ROOT)
         achieved = flops / (kernel_ms * 1e-3) / 1e12
+        # per kernel: the counting variant's counters split by kernel (rt_last_kernel_stats) x the same constants, over that
+        # kernel's busy time per frame in the committed trace.  Kernels of the two pipelines run side by side, so the busy
+        # times add up to more than the frame and a kernel's fraction is what it reaches while it shares the chip.
+        per_kernel, busy_src = None, None
+        if self.world == 1 and not width:
+            busy, busy_src = kernel_busy_ms(name, base_spp)
+            if busy:
+                per_kernel = {}
+                for k in KERNELS:
+                    f_k = algorithmic_flops(st["kernels"][k])
+                    b = busy.get(k)
+                    per_kernel[k] = {"flops": f_k, "busy_ms": b, "tflops": (f_k / (b * 1e-3) / 1e12) if b else None,
+                                     "frac": (f_k / (b * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS) if b else None}
+                per_kernel["fold"] = {"flops": 3.0 * total_paths, "busy_ms": busy.get("fold"), "tflops": None, "frac": None}
         out = {
             "value": total_rays * steps / elapsed / 1e6, "unit": "Mrays/s", "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3,
@@ -208,8 +246,10 @@ class Bench:
                          "kernel": "one rt_render call = the wavefront pipeline (rtk::wf_generate_kernel, wf_traverse_kernel, "
                                    "wf_shade_kernel, wf_tail_kernel, wf_fold_kernel)",
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
+                         "kernels": per_kernel, "kernels_busy_from": busy_src,
                          "note": "no dense contraction -> FP32 vector roofline (SURVEY.md 8d); flops = work counters x per-unit constants; "
                                  "kernel_ms = HIP events on the caller's stream around the call (the pipelines' streams fork from and join it); "
+                                 "kernels = per kernel: counters of that kernel (rt_last_kernel_stats) x the same constants over its busy time per frame in the committed kernel trace; "
                                  "traffic = FETCH_SIZE*2 + WRITE_SIZE bytes per step over all kernels, from " + (traffic_src or "n/a")},
         }
         if cpu:
@@ -304,6 +344,7 @@ def main():
                          "rays_per_step": r["rays_per_step"], "node_visits_per_ray": r["node_visits_per_ray"],
                          "box_tests_per_ray": r["box_tests_per_ray"], "roofline_frac": r["roofline"]["frac"],
                          "achieved_tflops": r["roofline"]["achieved"], "kernel_ms": r["roofline"]["kernel_ms"], "traffic": r["roofline"]["traffic"],
+                         "kernels": r["roofline"]["kernels"],
                          "bvh": r["config"]["bvh"], "bvh_nodes": r["config"]["bvh_nodes"], "primitives": r["config"]["primitives"],
                          "phase_occupancy": r["phase_occupancy"]}
     if rank == 0:

@@ -256,6 +256,12 @@ int rt_sampler_upload(rt_ctx *ctx, const rt_sampler_desc *sampler);
  * (path pool 1.2 GB, sample buffer up to RT_WF_SAMPLES_MB = 8192 MB; grown on demand). */
 int rt_render(rt_ctx *ctx, const rt_render_params *params, float *out_rgba_sum, rt_stats *stats);
 
+/* The counters of the last rt_render with collect_stats = 1, split by the kernel that did the work: 0 generate (camera rays and
+ * the part of world.hit() that precedes the walk, for new paths), 1 traverse (the BVH walk), 2 shade (ray_color's body and the
+ * next ray's start), 3 tail (all three for the last paths of a batch).  The four add up to rt_render's rt_stats.  Measurement only —
+ * NO COUNTERPART IN THE REFERENCE (it has no counters): bench.py prices each kernel's work against that kernel's time. */
+int rt_last_kernel_stats(rt_ctx *ctx, int32_t kernel, rt_stats *out);
+
 /* Gamma / validity pass, main.rs:1363-1388:  c = clamp(sqrt(sum/spp),0,1), !is_normal(sum) -> 0,
  * alpha copied.  location applies to both pointers; stream as in rt_render (NULL = default). */
 int rt_resolve(rt_ctx *ctx, const float *rgba_sum, int32_t n_pixels, int32_t spp,
@@ -275,13 +281,16 @@ int rt_resolve_rgb8(rt_ctx *ctx, const float *rgba_sum, int32_t n_pixels, int32_
 int rt_trace_first_hit(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_min, float t_max,
                        uint32_t *prim_id, float *t, float *normal3, uint8_t *front_face, float *uv2);
 
-/* rt_trace_first_hit for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, same kernel, same results; the staging
- * of rays and results and the traversal-stack overflow live in a static device array of RT_NOALLOC_SCRATCH_BYTES per GPU
- * (held from library load to process exit) instead of a buffer allocated per call, and the call makes no hipMalloc / hipFree.
+/* rt_trace_first_hit for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc,
+ * hosts that must not touch the allocator while something else is being captured into a graph).  NO COUNTERPART IN THE
+ * REFERENCE.  Same arguments, same kernel, same results; the staging of rays and results and the traversal-stack overflow live
+ * in a static device array of RT_NOALLOC_SCRATCH_BYTES per GPU (held from library load to process exit) instead of a buffer
+ * allocated per call, and the call makes no hipMalloc / hipFree.  It is SYNCHRONOUS like rt_trace_first_hit — host pointers in,
+ * copies on the library's own stream, a stream synchronize before it returns — so it is not itself capturable into a graph.
  * n is limited by that array: 57 bytes per ray plus 4 bytes per ray and BVH stack level beyond 48 (about 147 000 rays for the
  * BASELINE scenes); a larger batch returns RT_E_INVALID with the limit in rt_last_error() and touches nothing.
- * All contexts of one GPU share its array: calls that overlap in time on one GPU race (serialise them). */
+ * All contexts of one GPU share its array: the library serialises the calls of one process on one GPU (a mutex per device; the
+ * call blocks anyway); calls from different PROCESSES have their own copies of the array. */
 #define RT_NOALLOC_SCRATCH_BYTES (8u << 20)
 int rt_trace_first_hit_noalloc(rt_ctx *ctx, const float *rays_soa, int32_t n, float t_min, float t_max,
                                uint32_t *prim_id, float *t, float *normal3, uint8_t *front_face, float *uv2);
@@ -309,6 +318,8 @@ typedef struct rt_comm rt_comm;
 int rt_comm_unique_id(char id[RT_COMM_ID_BYTES]);
 int rt_comm_create(rt_ctx *ctx, const char id[RT_COMM_ID_BYTES], int rank, int world, rt_comm **out);
 int rt_comm_reduce_to_root(rt_comm *comm, float *rgba_sum_device, int64_t n_floats, int root, void *stream);
+/* (rt_comm_reduce_to_root needs the communicator's context alive — it reports errors there; rt_comm_destroy does not touch the
+ * context and may run after rt_destroy.) */
 void rt_comm_destroy(rt_comm *comm);
 
 /* One process, n GPUs (what a Rust host with one thread per GPU would use): a group owns one context per listed device and a

@@ -241,6 +241,7 @@ extern "C" {
                               normal3: *mut f32, front_face: *mut u8, uv2: *mut f32) -> c_int;
     pub fn rt_trace_first_hit_noalloc(ctx: *mut rt_ctx, rays_soa: *const f32, n: i32, t_min: f32, t_max: f32, prim_id: *mut u32, t: *mut f32,
                                       normal3: *mut f32, front_face: *mut u8, uv2: *mut f32) -> c_int;
+    pub fn rt_last_kernel_stats(ctx: *mut rt_ctx, kernel: i32, out: *mut rt_stats) -> c_int;
     pub fn rt_synchronize(ctx: *mut rt_ctx, stream: *mut c_void) -> c_int;
     pub fn rt_device_info(ctx: *mut rt_ctx, name: *mut c_char, name_len: i32, cu_count: *mut i32, clock_mhz: *mut i32) -> c_int;
     // multi-GPU

@@ -190,7 +190,7 @@ HOST_SYMBOLS = [
 HIP_SYMBOLS = [
     "rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_scene_upload", "rt_sampler_upload", "rt_render",
     "rt_resolve", "rt_trace_first_hit", "rt_synchronize", "rt_device_info", "rt_scene_query", "rt_scene_read_bvh", "rt_resolve_rgb8",
-    "rt_trace_first_hit_noalloc",
+    "rt_trace_first_hit_noalloc", "rt_last_kernel_stats",
     "rt_comm_unique_id", "rt_comm_create", "rt_comm_reduce_to_root", "rt_comm_destroy",
     "rt_device_alloc", "rt_device_free", "rt_device_zero", "rt_device_read",
     "rt_group_create", "rt_group_size", "rt_group_ctx", "rt_group_reduce_to_root", "rt_group_destroy",
@@ -311,6 +311,7 @@ def hip_lib():
     L.rt_trace_first_hit.argtypes = [vp, c_float_p, i32, C.c_float, C.c_float, c_u32_p, c_float_p, c_float_p, c_u8_p,
                                      c_float_p]
     L.rt_trace_first_hit_noalloc.argtypes = L.rt_trace_first_hit.argtypes
+    L.rt_last_kernel_stats.argtypes = [vp, i32, C.POINTER(rt_stats)]
     L.rt_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.rt_device_free.argtypes = [vp, vp]
     L.rt_device_zero.argtypes = [vp, vp, C.c_size_t, vp]

@@ -111,7 +111,18 @@ class HipBackend:
         p.collect_stats = 1
         st = _ffi.rt_stats()
         self._check(self._L.rt_render(self._h, C.byref(p), out_ptr, C.byref(st)))
-        return st.as_dict()
+        out = st.as_dict()
+        out["kernels"] = self.last_kernel_stats()
+        return out
+
+    def last_kernel_stats(self):
+        """rt_last_kernel_stats: the counters of the last counting render by kernel (they add up to its rt_stats)."""
+        res = {}
+        for k, name in enumerate(("generate", "traverse", "shade", "tail")):
+            st = _ffi.rt_stats()
+            self._check(self._L.rt_last_kernel_stats(self._h, k, C.byref(st)))
+            res[name] = st.as_dict()
+        return res
 
     def resolve(self, sum_rgba, spp):
         s = np.ascontiguousarray(sum_rgba, np.float32)

@@ -82,7 +82,8 @@ const char *rccl_unavailable() { rccl(); static Rccl dummy; (void)dummy; return 
 }  // namespace
 
 struct rt_comm {
-    rt_ctx *ctx = nullptr;
+    rt_ctx *ctx = nullptr;        // for error messages of rt_comm_reduce_to_root only (the context must be alive for that call)
+    int device = 0;               // the context's device, kept here: rt_comm_destroy may run after the context is gone
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
 };
@@ -159,7 +160,7 @@ int rt_comm_create(rt_ctx *ctx, const char id[RT_COMM_ID_BYTES], int rank, int w
     if (hipSetDevice(ctx_device(ctx)) != hipSuccess) return ctx_fail(ctx, RT_E_HIP, "rt_comm_create: hipSetDevice(%d) failed", ctx_device(ctx));
     rt_comm *c = new (std::nothrow) rt_comm();
     if (!c) return ctx_fail(ctx, RT_E_OOM, "out of host memory");
-    c->ctx = ctx; c->rank = rank; c->world = world;
+    c->ctx = ctx; c->device = ctx_device(ctx); c->rank = rank; c->world = world;
     ncclUniqueId u;
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     ncclResult_t r = R->CommInitRank(&c->comm, world, u, rank);
@@ -174,7 +175,7 @@ int rt_comm_reduce_to_root(rt_comm *c, float *rgba_sum, int64_t n_floats, int ro
     if (n_floats == 0) return RT_OK;
     const Rccl *R = rccl();
     if (!R) return ctx_fail(c->ctx, RT_E_RCCL, "%s", rccl_unavailable());
-    if (hipSetDevice(ctx_device(c->ctx)) != hipSuccess) return ctx_fail(c->ctx, RT_E_HIP, "rt_comm_reduce_to_root: hipSetDevice failed");
+    if (hipSetDevice(c->device) != hipSuccess) return ctx_fail(c->ctx, RT_E_HIP, "rt_comm_reduce_to_root: hipSetDevice failed");
     // in place: on the root the sums of all ranks arrive in rgba_sum, on the others it is only read
     RCCL_TRY(c->ctx, R, R->Reduce(rgba_sum, rgba_sum, (size_t)n_floats, ncclFloat, ncclSum, root, c->comm, (hipStream_t)stream));
     return RT_OK;
@@ -183,7 +184,7 @@ int rt_comm_reduce_to_root(rt_comm *c, float *rgba_sum, int64_t n_floats, int ro
 void rt_comm_destroy(rt_comm *c) {
     if (!c) return;
     const Rccl *R = rccl();
-    if (R && c->comm) { (void)hipSetDevice(ctx_device(c->ctx)); (void)R->CommDestroy(c->comm); }
+    if (R && c->comm) { (void)hipSetDevice(c->device); (void)R->CommDestroy(c->comm); }      // (touches no context: see rt_comm::device)
     delete c;
 }
 

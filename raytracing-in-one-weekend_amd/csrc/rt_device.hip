@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -34,7 +35,10 @@ struct rt_ctx {
     bool bvh_has_general_xform = false;   // some slot under a general Transform sits in a BVH leaf
     int features = EXT_ALL;               // EXT_* bits the uploaded scene needs (rt_kernels.h); picks the kernel set
     float bvh_build_ms = 0.0f;
-    unsigned long long *d_stats = nullptr;  // 128 words: counters + region timers of a render, the tail kernel's own timers from word 64 (development builds)
+    unsigned long long *d_stats = nullptr;  // RT_STATS_TOTAL_WORDS: counters + region timers of a render, the tail kernel's own timers from word 64
+                                            // (development builds), the counters per kernel from word RT_KSTAT_BASE (counting variant)
+    rt_stats kernel_stats[RT_K_COUNT] = {}; // ... of the last render with collect_stats (rt_last_kernel_stats)
+    bool have_kernel_stats = false;
     hipDeviceProp_t prop{};
     // wavefront workspace (grown on demand, kept until rt_destroy)
     void *wf_pool = nullptr;      size_t wf_pool_entries = 0;   // 2 buffers x entries x 72 B
@@ -59,6 +63,7 @@ namespace {
 
 constexpr int kMaxDevices = 64;
 void *g_noalloc_ptr[kMaxDevices] = {};   // device address of g_noalloc_scratch on each device (set once by rt_create, same value every time)
+std::mutex g_noalloc_mutex[kMaxDevices]; // rt_trace_first_hit_noalloc: one call at a time per device
 
 thread_local std::string g_create_error;
 
@@ -130,6 +135,7 @@ template <bool STATS> struct WfKernels {
     decltype(&wf_shade_kernel<STATS, KS_CHAIN>) shade;
     decltype(&wf_tail_kernel<STATS, KS_CHAIN>) tail;
     decltype(&wf_traverse_kernel<STATS, EXT_NONE>) traverse;
+    decltype(&wf_traverse_kernel<STATS, EXT_NONE, true>) traverse_top;   // ... with the top of the tree in LDS (TopLds)
 };
 template <bool STATS, int KS> WfKernels<STATS> wf_kernels_of(bool tree_has_xform, bool tree_has_tris) {
     constexpr int XF = EXT_XFORM | EXT_TRI | (KS & EXT_CHAIN);
@@ -139,6 +145,7 @@ template <bool STATS, int KS> WfKernels<STATS> wf_kernels_of(bool tree_has_xform
     k.tail = wf_tail_kernel<STATS, KS>;
     // the walk's leaf step: spheres and rectangles, + triangles, + slots under a general Transform
     k.traverse = tree_has_xform ? wf_traverse_kernel<STATS, XF> : tree_has_tris ? wf_traverse_kernel<STATS, EXT_TRI> : wf_traverse_kernel<STATS, EXT_NONE>;
+    k.traverse_top = tree_has_xform ? wf_traverse_kernel<STATS, XF, true> : tree_has_tris ? wf_traverse_kernel<STATS, EXT_TRI, true> : wf_traverse_kernel<STATS, EXT_NONE, true>;
     return k;
 }
 template <bool STATS> WfKernels<STATS> wf_kernels(int features, bool tree_has_xform) {
@@ -158,6 +165,7 @@ template <bool STATS> WfKernels<STATS> wf_kernels(int features, bool tree_has_xf
 
 constexpr int kMaxPipes = 4;
 constexpr uint32_t kMaxStackDepth = 256;   // traversal stack entries; beyond the LDS part they live in HBM
+constexpr size_t kMaxTopNodes = 1024;      // breadth-first table of the tree's top (DScene::top_order): more than any launch stages
 constexpr size_t kEntryBytes = 72;   // rt_wavefront.h: 4 float4 + 1 float2 per pool entry
 
 PathQ pool_buffer(rt_ctx *ctx, int which) {
@@ -214,6 +222,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     const size_t need_samples = spp_batch_max * per_sample;
     int n_pipes = (int)env_size("RT_WF_PIPES", 2, 1, kMaxPipes);
     if (need_samples < 4 * shard_q || n_tiles < 2u) n_pipes = 1;
+    if ((uint32_t)n_pipes > n_tiles) n_pipes = (int)n_tiles;      // every pipeline gets at least one tile (magic_div(tiles_pipe) divides by it)
     size_t pool_want = ((size_t)1 << env_size("RT_WF_POOL_LOG2", 23, 14, 26)) / (size_t)n_pipes;   // per pipeline
     pool_want = pool_want / shard_q * shard_q;
     if (pool_want < shard_q) pool_want = shard_q;
@@ -262,15 +271,22 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         ctx->wf_ready = true;
     }
     // traversal stack: the first lds_depth entries of every lane in LDS, the (rarely reached) rest in HBM
-    const uint32_t lds_want = (uint32_t)env_size("RT_WF_LDS_DEPTH", 20, 1, 64);
+    // The top of the tree (breadth-first) in LDS behind the stacks (rt_kernels.h, TopLds).  Measured (profiles/r3/
+    // ab_traverse_top_nodes_lds*.txt): a tree that fits whole (Book-1: 234 nodes, 15 KB) with 12 stack levels in LDS instead of
+    // 20 is worth 2.6 % of the 10-spp frame and 4 % at 100 spp; the top 44-170 nodes of a larger tree (Book-2: 1 170 nodes, the
+    // mesh: 400 000) are worth nothing (-2 ... +0.3 %), so those keep the LDS for stacks and waves.
+    const bool small_tree = ctx->sc.n_top != 0 && ctx->n_bvh_nodes <= 256u;
+    const uint32_t top_want = (uint32_t)env_size("RT_WF_TOP_NODES", small_tree ? 256 : 0, 0, kMaxTopNodes);
+    const uint32_t n_top = top_want < ctx->sc.n_top ? top_want : ctx->sc.n_top;
+    const uint32_t lds_want = (uint32_t)env_size("RT_WF_LDS_DEPTH", n_top ? 12 : 20, 1, 64);
     const uint32_t lds_depth = lds_want < ctx->stack_depth ? lds_want : ctx->stack_depth;
-    const size_t lds = (size_t)lds_depth * 256 * sizeof(StackEntry);
+    const size_t lds = (size_t)lds_depth * 256 * sizeof(StackEntry) + (size_t)n_top * 64;
     int per_cu = 0;
     // two instances of the traversal kernel: scenes with a general Transform inside the BVH need the code for it in the leaf step
     int features = ctx->features;
     if (const char *e = getenv("RT_KERNEL_SET")) { if (!strcmp(e, "full")) features |= KS_FULL; }   // A/B: run a scene on the full set
     const WfKernels<STATS> K = wf_kernels<STATS>(features, ctx->bvh_has_general_xform);
-    auto *const trav_kernel = K.traverse;
+    auto *const trav_kernel = n_top ? K.traverse_top : K.traverse;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel, 256, lds));
     {   // the runtime's answer may assume the 64 KB per-workgroup LDS limit; gfx950 has 160 KB per CU
         hipFuncAttributes fa{};
@@ -293,7 +309,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     }
     const bool debug = getenv("RT_DEBUG") != nullptr;
     unsigned long long *d_stats = (STATS || kTimers) ? ctx->d_stats : nullptr;
-    if (STATS || kTimers) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 128 * sizeof(unsigned long long), stream));
+    if (STATS || kTimers) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, RT_STATS_TOTAL_WORDS * sizeof(unsigned long long), stream));
     // the tail kernel (rt_wavefront.h): once every item is out and at most RT_WF_TAIL paths live, an iteration is RT_WF_TAIL_BOUNCES
     // bounces of every path in one launch instead of traverse + shade; 0 = never.  Measured on MI355X against 0: C1 at 10 spp
     // 5.2 -> 3.1 ms, C4 at 4 spp +40 %, C2 at 16 spp +18 %, the long renders +1 %.
@@ -397,7 +413,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             const bool near_end = (uint64_t)(P.w.n_items - P.known_out) <= 8ull * (uint64_t)P.w.pool;
             const uint32_t with_tail = tail_max && (P.items_out || (near_end && (int)(it % (uint32_t)tail_every) == tail_every - 1)) ? 1u : 0u;
             if (has_bvh) hipLaunchKernelGGL(trav_kernel, dim3(P.trav_blocks), dim3(256), lds, P.s, ctx->sc, cur, P.ctr, it, P.w.cap,
-                                            lds_depth, P.ovf, d_stats, with_tail);
+                                            lds_depth, P.ovf, d_stats, with_tail, n_top);
             hipLaunchKernelGGL(K.shade, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
                                ctx->wf_samples, d_stats, d_rays, with_tail);
             if (with_tail)
@@ -517,7 +533,7 @@ int rt_create(int device_id, rt_ctx **out) {
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_stats, 128 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_stats, RT_STATS_TOTAL_WORDS * sizeof(unsigned long long));
     if (e == hipSuccess && device_id < kMaxDevices) {   // this device's copy of the static scratch array (device_id is current)
         void *p = nullptr;
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch));
@@ -725,10 +741,25 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
             if (!(type == RT_PRIM_SPHERE || (type >= RT_PRIM_XY_RECT && type <= RT_PRIM_YZ_RECT)) || (flags & 12))
                 return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "medium %u: boundary slot %d is not a sphere or rectangle under Translate / RotateY", i, k);
         }
-        int32_t tex, tkind;
+        // the phase function's texture: an Isotropic material (the one kind ConstantMedium::new makes, constant_medium.rs:22-38; its
+        // texture index was range-checked above) whose texture reads no u, v — the kernels keep no u, v of a boundary slot's hit.  The
+        // walk is texture_needs_uv()'s (rt_kernels.h): an image, or a checker with an image anywhere below it.
+        int32_t mtype, tex;
+        memcpy(&mtype, &s->materials[(size_t)mat * RT_REC_FLOATS], 4);
         memcpy(&tex, &s->materials[(size_t)mat * RT_REC_FLOATS + 1], 4);
-        memcpy(&tkind, &s->textures[(size_t)tex * RT_REC_FLOATS], 4);
-        if (tkind == RTG_TEX_IMAGE) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "medium %u: an image texture on a non-sphere boundary is not supported (u, v of the boundary hit)", i);
+        if (mtype != RTG_MAT_ISOTROPIC) return fail(ctx, RT_E_INVALID, "medium %u: material %d is not Isotropic", i, mat);
+        bool reads_uv = false;
+        std::vector<int32_t> todo(1, tex);
+        for (size_t seen = 0; !todo.empty() && !reads_uv; ++seen) {
+            if (seen > 4096) { reads_uv = true; break; }                  // a cycle of checkers: be conservative
+            const int32_t t = todo.back();
+            todo.pop_back();
+            int32_t w[8];
+            memcpy(w, &s->textures[(size_t)t * RT_REC_FLOATS], 32);       // (checker children were range-checked above)
+            if (w[0] == RTG_TEX_IMAGE) reads_uv = true;
+            else if (w[0] == RTG_TEX_CHECKER) { todo.push_back(w[4]); todo.push_back(w[5]); }
+        }
+        if (reads_uv) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "medium %u: an image texture on a non-sphere boundary is not supported (u, v of the boundary hit)", i);
     }
 
     int st = set_device(ctx);
@@ -740,6 +771,28 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     auto &own = ctx->scene_allocs;
 #define UP(field, src, bytes) if ((st = upload(ctx, own, src, bytes, &d.field)) != RT_OK) return st
     if (!device_build) UP(nodes, s->bvh_nodes, (size_t)s->n_bvh_nodes * RT_NODE_FLOATS * 4);
+    d.n_top = 0;
+    {   // the top of the tree in breadth-first order (DScene::top_order / top_child), for the walk that keeps it in LDS
+        std::vector<uint32_t> order, child;
+        if (!device_build && s->bvh_root_ref != RT_BVH_EMPTY && s->bvh_root_ref >= 0) {
+            std::vector<uint32_t> place(s->n_bvh_nodes, 0xffffffffu);
+            order.push_back((uint32_t)s->bvh_root_ref);
+            place[(size_t)s->bvh_root_ref] = 0;
+            for (size_t k = 0; k < order.size(); ++k) {       // (the queue is the order itself)
+                int32_t refs[4];
+                memcpy(refs, &s->bvh_nodes[(size_t)order[k] * RT_NODE_FLOATS + 12], 16);
+                for (int32_t r : refs) {
+                    uint32_t at = 0xffffffffu;
+                    if (r >= 0 && r != RT_BVH_EMPTY && order.size() < kMaxTopNodes) { at = (uint32_t)order.size(); place[(size_t)r] = at; order.push_back((uint32_t)r); }
+                    child.push_back(at);
+                }
+            }
+            d.n_top = (uint32_t)order.size();
+        }
+        UP(top_order, order.data(), order.size() * 4);
+        UP(top_child, child.data(), child.size() * 4);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the vectors go out of scope
+    }
     {   // device copy of the slots: spheres and rectangles under a transform get that transform's record in
         // words 8..15 (rt_kernels.h SlotRec), so a hit test is one 64-byte fetch
         std::vector<float> dev_slots(s->slots, s->slots + (size_t)s->n_slots * RT_SLOT_FLOATS);
@@ -985,7 +1038,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
         }
     }
     hipError_t e = hipGetLastError();
-    unsigned long long h_stats[64] = {};
+    unsigned long long h_stats[RT_STATS_TOTAL_WORDS] = {};
     if (e == hipSuccess && p->collect_stats) {
         e = hipMemcpyAsync(h_stats, ctx->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -999,17 +1052,30 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
     if (tmp_rays) (void)hipFree(tmp_rays);
     if (e != hipSuccess) return fail(ctx, RT_E_HIP, "rt_render: %s", hipGetErrorString(e));
     if (p->collect_stats) {
-        memset(stats, 0, sizeof *stats);
-        stats->paths = h_stats[0]; stats->rays = h_stats[1]; stats->node_visits = h_stats[2];
-        constexpr int P = RT_N_PRIM_TYPES;   // order: flush_counters (rt_wavefront.h)
-        for (int i = 0; i < P; ++i) stats->prim_tests[i] = h_stats[3 + i];
-        stats->medium_tests = h_stats[3 + P]; stats->light_pdf_evals = h_stats[4 + P];
-        for (int i = 0; i < 5; ++i) stats->shades[i] = h_stats[5 + P + i];
-        for (int i = 0; i < 4; ++i) stats->tex_evals[i] = h_stats[10 + P + i];
-        stats->accepted_hits = h_stats[14 + P];
-        for (int i = 0; i < 5; ++i) { stats->phase_lanes[i] = h_stats[15 + P + i]; stats->phase_slots[i] = h_stats[20 + P + i]; }
-        stats->box_tests = h_stats[25 + P];
+        auto unpack = [](const unsigned long long *h, rt_stats *st) {
+            memset(st, 0, sizeof *st);
+            st->paths = h[0]; st->rays = h[1]; st->node_visits = h[2];
+            constexpr int P = RT_N_PRIM_TYPES;   // order: flush_counters (rt_wavefront.h)
+            for (int i = 0; i < P; ++i) st->prim_tests[i] = h[3 + i];
+            st->medium_tests = h[3 + P]; st->light_pdf_evals = h[4 + P];
+            for (int i = 0; i < 5; ++i) st->shades[i] = h[5 + P + i];
+            for (int i = 0; i < 4; ++i) st->tex_evals[i] = h[10 + P + i];
+            st->accepted_hits = h[14 + P];
+            for (int i = 0; i < 5; ++i) { st->phase_lanes[i] = h[15 + P + i]; st->phase_slots[i] = h[20 + P + i]; }
+            st->box_tests = h[25 + P];
+        };
+        unpack(h_stats, stats);
+        for (int k = 0; k < RT_K_COUNT; ++k) unpack(h_stats + RT_KSTAT_BASE + 64 * k, &ctx->kernel_stats[k]);
+        ctx->have_kernel_stats = true;
     }
+    return RT_OK;
+}
+
+int rt_last_kernel_stats(rt_ctx *ctx, int32_t kernel, rt_stats *out) {
+    if (!ctx) return RT_E_INVALID;
+    if (!out || kernel < 0 || kernel >= RT_K_COUNT) return fail(ctx, RT_E_INVALID, "rt_last_kernel_stats: kernel %d (0 generate, 1 traverse, 2 shade, 3 tail)", kernel);
+    if (!ctx->have_kernel_stats) return fail(ctx, RT_E_INVALID, "rt_last_kernel_stats: no render with collect_stats yet");
+    *out = ctx->kernel_stats[kernel];
     return RT_OK;
 }
 
@@ -1150,7 +1216,11 @@ int rt_trace_first_hit_noalloc(rt_ctx *ctx, const float *rays_soa, int32_t n, fl
     }
     int st = set_device(ctx);
     if (st) return st;
-    hipError_t e = first_hit_run(ctx, ctx->noalloc_scratch, L, rays_soa, n, t_min, t_max, prim_id, t, normal3, front_face, uv2);
+    hipError_t e;
+    {   // every context of this process on this GPU shares the one array: one call at a time (the call blocks to its end anyway)
+        std::lock_guard<std::mutex> hold(g_noalloc_mutex[ctx->device < kMaxDevices ? ctx->device : 0]);
+        e = first_hit_run(ctx, ctx->noalloc_scratch, L, rays_soa, n, t_min, t_max, prim_id, t, normal3, front_face, uv2);
+    }
     if (e != hipSuccess) return fail(ctx, RT_E_HIP, "rt_trace_first_hit_noalloc: %s", hipGetErrorString(e));
     return RT_OK;
 }

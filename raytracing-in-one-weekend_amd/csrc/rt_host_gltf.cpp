@@ -357,8 +357,12 @@ struct Importer {
             const J *bv = imgs->arr[i].get("bufferView");
             if (!bv || !views || bv->as_int() < 0 || (size_t)bv->as_int() >= views->arr.size()) continue;
             const J &view = views->arr[bv->as_int()];
-            const size_t off = (size_t)(view.get("byteOffset") ? view.get("byteOffset")->num : 0), len = (size_t)(view.get("byteLength") ? view.get("byteLength")->num : 0);
-            if ((view.get("buffer") && view.get("buffer")->as_int(0) != 0) || !len || off + len > bin_len) continue;
+            // offsets and lengths are JSON numbers: anything that is not a whole number inside the BIN chunk (negative, NaN, 1e300 —
+            // a cast of those is undefined, and a sum that wraps would pass the range check) leaves the image empty
+            const double off_d = view.get("byteOffset") ? view.get("byteOffset")->num : 0.0, len_d = view.get("byteLength") ? view.get("byteLength")->num : 0.0;
+            if (!(off_d >= 0.0 && off_d <= (double)bin_len) || !(len_d >= 1.0 && len_d <= (double)bin_len)) continue;
+            const size_t off = (size_t)off_d, len = (size_t)len_d;
+            if ((view.get("buffer") && view.get("buffer")->as_int(0) != 0) || len > bin_len || off > bin_len - len) continue;
             int32_t w = 0, h = 0;
             uint8_t *px = nullptr;
             if (rth_image_decode(bin + off, len, &w, &h, &px) != RT_OK) continue;

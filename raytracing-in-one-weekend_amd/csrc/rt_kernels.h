@@ -99,6 +99,12 @@ struct DScene {
     const uint32_t *shuffled;
     int32_t root_ref;
     uint32_t n_slots, always_begin, always_count, n_media, n_lights, n_moving, n_rects, sets, spp;
+    // The top of the tree in breadth-first order, for the walk that keeps it in LDS (wf_traverse_kernel, TopLds): node index of
+    // the k-th node from the root, and for each of its four children that child's own place in that order (or ~0u: a leaf, no
+    // child, or further down than the table goes).  n_top entries (0: no table — a tree built on the device).
+    const uint32_t *top_order;
+    const uint32_t *top_child;
+    uint32_t n_top;
 };
 
 #define RT_N_REGIONS 24
@@ -236,6 +242,32 @@ RT_DEV SlotRec load_slot(const DScene &sc, uint32_t slot) {
     SlotRec s;
     s.q0 = p[0]; s.meta = p[1]; s.q2 = p[2]; s.q3 = p[3];
     return s;
+}
+// load_slot() for a slot index that is the same in every lane of the wave (the always-list scan): through a pointer in the
+// constant address space the four quads are ONE scalar load (s_load_dwordx16 into SGPRs, through the scalar cache) instead of four
+// vector loads of one address by 64 lanes — no vector-memory instruction, no trip through the texture data path, and the slot's
+// 16 words cost no vector registers while the next one is being fetched.  The slot array is read-only for every kernel.
+// Measured (profiles/r3/ab_always_scalar_loads.txt): Blocks +3.6 %, GeometricPrimitives +2.7 %, the Cornell box with smoke +1.6 %,
+// but the plain Cornell box -1.8 % (its small kernel set has the registers to fetch a slot ahead as a vector load, and a scalar
+// load is waited for in order): so the small set keeps the vector loads.
+#ifndef RT_ALWAYS_SCALAR
+#define RT_ALWAYS_SCALAR 1
+#endif
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+template <int EXT>
+RT_DEV SlotRec load_slot_uniform(const DScene &sc, uint32_t slot) {
+    if ((EXT & EXT_ALL) == EXT_NONE) return load_slot(sc, slot);
+#if RT_ALWAYS_SCALAR
+    typedef const __attribute__((address_space(4))) f32x4c *ConstQuad;
+    const ConstQuad p = (ConstQuad)(uintptr_t)(sc.slots + 4 * (size_t)slot);
+    const f32x4c a = p[0], b = p[1], c = p[2], d = p[3];
+    SlotRec s;
+    s.q0 = make_float4(a.x, a.y, a.z, a.w); s.meta = make_float4(b.x, b.y, b.z, b.w);
+    s.q2 = make_float4(c.x, c.y, c.z, c.w); s.q3 = make_float4(d.x, d.y, d.z, d.w);
+    return s;
+#else
+    return load_slot(sc, slot);
+#endif
 }
 __host__ __device__ inline bool type_has_inline_xform(int type) { return type != RT_PRIM_MOVING_SPHERE && type != RT_PRIM_TRIANGLE && type != RT_PRIM_HYPERBOLOID; }
 
@@ -636,10 +668,33 @@ RT_DEV int32_t pop_ref(const Stack &st, uint32_t &sp) {
 // the parameter fma(q, sx, ox) falls as q grows, so it is the upper plane; the rounding of an fma is monotone, so this is
 // the min / max of the two parameters exactly) — six selects per node instead of six min / max per child; (key, ref) pairs
 // go through the sorting network together, so no child ref is looked up by index afterwards.
-template <bool STATS>
-RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t_min, float best_t, const Stack &stack, uint32_t &sp, Counters &cnt) {
-    const float4 *n = sc.nodes + 4 * (size_t)ref;
-    const float4 n0 = n[0], n1 = n[1], n2 = n[2], rf = n[3];
+// The first `count` nodes of the tree in breadth-first order as a traversal workgroup holds them in LDS: the four 16-byte quarters
+// of the records as four planes (quarter q of the k-th node at [q * count + k], so a wave's reads of one quarter of 64 different
+// nodes spread over the banks).  A ref with RT_TOP_FLAG names a node of this image by its place k; the image's own child refs
+// are rewritten accordingly when it is staged.  Every other ref is what it is everywhere else (a node of sc.nodes, a leaf, nothing).
+// What it is for: the walk's node fetches return through the vector memory's data path (64 B per clock and CU), which PMC
+// shows busy 60-75 % of a traversal launch — more than its vector ALUs; the nodes near the root are the ones every ray visits,
+// and from LDS they cost that path nothing.
+#define RT_TOP_FLAG 0x40000000
+typedef float f32x4 __attribute__((ext_vector_type(4)));      // (a builtin vector: HIP's float4 class would be copied through a generic reference)
+typedef const RT_LDS f32x4 *LdsF4Ptr;
+RT_DEV float4 lds_f4(LdsF4Ptr p) { const f32x4 v = *p; return make_float4(v.x, v.y, v.z, v.w); }
+struct TopLds {
+    LdsF4Ptr img;
+    uint32_t count;
+};
+
+template <bool STATS, bool LT = false>
+RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t_min, float best_t, const Stack &stack, uint32_t &sp, Counters &cnt,
+                           const TopLds &top = TopLds{(LdsF4Ptr)0, 0u}) {
+    float4 n0, n1, n2, rf;
+    if (LT && (ref & RT_TOP_FLAG)) {
+        const LdsF4Ptr n = top.img + (uint32_t)(ref & ~RT_TOP_FLAG);
+        n0 = lds_f4(n); n1 = lds_f4(n + top.count); n2 = lds_f4(n + 2u * top.count); rf = lds_f4(n + 3u * top.count);
+    } else {
+        const float4 *n = sc.nodes + 4 * (size_t)ref;
+        n0 = n[0]; n1 = n[1]; n2 = n[2]; rf = n[3];
+    }
     // plane = origin + scale * q, so its ray parameter (plane - o) * inv is q * (scale * inv) + (origin * inv - o * inv)
     const float sx = n0.w * inv.x, sy = n1.x * inv.y, sz = n1.y * inv.z;
     const float ox = __builtin_fmaf(n0.x, inv.x, -oi.x), oy = __builtin_fmaf(n0.y, inv.y, -oi.y), oz = __builtin_fmaf(n0.z, inv.z, -oi.z);
@@ -826,13 +881,13 @@ template <bool STATS, int EXT = EXT_ALL>
 RT_DEV void always_scan(const DScene &sc, const Ray &r, float t_min, float t_max, int32_t floor_id, Hit &best, Counters &cnt) {
 #if !RT_ALWAYS_FILTER
     if (sc.always_count) {   // the slot index is wave-uniform: fetch slot i+1 while slot i is tested
-        SlotRec nx = load_slot(sc, sc.always_begin);
+        SlotRec nx = load_slot_uniform<EXT>(sc, sc.always_begin);
         int frame_xf = -1;   // consecutive slots under one transform (the six sides of a block) share the transformed ray
         Ray r_frame = r;
         for (uint32_t i = 0; i < sc.always_count; ++i) {
             const SlotRec cu = nx;
             const uint32_t s = sc.always_begin + i;
-            if (i + 1 < sc.always_count) nx = load_slot(sc, s + 1);
+            if (i + 1 < sc.always_count) nx = load_slot_uniform<EXT>(sc, s + 1);
             const int w4 = f2i(cu.meta.x), xf = (w4 >> 8) - 1;   // wave-uniform
             if (xf != frame_xf) {
                 frame_xf = xf;
@@ -1063,10 +1118,10 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
     return true;
 }
 
-template <bool STATS>
-RT_DEV void trav_node_step(const DScene &sc, float t_min, Trav &tv, const Stack &stack, Counters &cnt) {
+template <bool STATS, bool LT = false>
+RT_DEV void trav_node_step(const DScene &sc, float t_min, Trav &tv, const Stack &stack, Counters &cnt, const TopLds &top = TopLds{(LdsF4Ptr)0, 0u}) {
     if (STATS) cnt.node_visits += 1;
-    tv.ref = node4_visit<STATS>(sc, tv.ref, tv.inv, tv.oi, t_min, tv.best.t, stack, tv.sp, cnt);
+    tv.ref = node4_visit<STATS, LT>(sc, tv.ref, tv.inv, tv.oi, t_min, tv.best.t, stack, tv.sp, cnt, top);
 }
 
 template <bool STATS, int EXT>

@@ -150,8 +150,13 @@ RT_DEV uint32_t wave_append_to(WfCounters *c, uint32_t cap, bool keep, uint32_t 
     return pos;
 }
 
+// `which` = the kernel the counters come from (RT_K_*): the counting variant keeps them per kernel as well (words
+// RT_KSTAT_BASE + 64 * which ..., rt_last_kernel_stats), so that the work of a frame can be priced kernel by kernel.
+enum { RT_K_GENERATE = 0, RT_K_TRAVERSE = 1, RT_K_SHADE = 2, RT_K_TAIL = 3, RT_K_COUNT = 4 };
+#define RT_KSTAT_BASE 128
+#define RT_STATS_TOTAL_WORDS (RT_KSTAT_BASE + 64 * RT_K_COUNT)
 template <bool STATS>
-RT_DEV void flush_counters(const Counters &cnt, uint32_t paths, unsigned long long *stats) {
+RT_DEV void flush_counters(const Counters &cnt, uint32_t paths, unsigned long long *stats, int which) {
     if (kTimers && !STATS) {
         for (int i = 0; i < RT_N_REGIONS; ++i) {
             uint32_t w = wave_sum(cnt.region[i]);
@@ -172,7 +177,7 @@ RT_DEV void flush_counters(const Counters &cnt, uint32_t paths, unsigned long lo
     vals[25 + P] = cnt.box_tests;
     for (int i = 0; i < RT_STAT_WORDS; ++i) {
         uint32_t w = wave_sum(vals[i]);
-        if ((threadIdx.x & 63u) == 0 && w) atomicAdd(&stats[i], (unsigned long long)w);
+        if ((threadIdx.x & 63u) == 0 && w) { atomicAdd(&stats[i], (unsigned long long)w); atomicAdd(&stats[RT_KSTAT_BASE + 64 * which + i], (unsigned long long)w); }
     }
 }
 
@@ -277,7 +282,7 @@ __global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScen
         const bool walk = begin_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt);
         store_entry(nxt, e, p, tv, walk);
     }
-    if (STATS || kTimers) flush_counters<STATS>(cnt, inside ? 1u : 0u, stats);
+    if (STATS || kTimers) flush_counters<STATS>(cnt, inside ? 1u : 0u, stats, RT_K_GENERATE);
 }
 
 /* ------------------------------------------------------------------ traverse */
@@ -308,9 +313,9 @@ __global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScen
 #ifndef RT_WF_TRAV_WAVES
 #define RT_WF_TRAV_WAVES 6      // min waves per SIMD the traverse kernel is compiled for (80 VGPRs, no spills)
 #endif
-template <bool STATS, int EXT>
+template <bool STATS, int EXT, bool LT = false>
 __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DScene sc, PathQ q, WfCounters *ctr, uint32_t it, uint32_t cap, uint32_t lds_depth,
-                                                          StackEntry *ovf, unsigned long long *stats, uint32_t with_tail) {
+                                                          StackEntry *ovf, unsigned long long *stats, uint32_t with_tail, uint32_t n_top) {
     extern __shared__ StackEntry lds_stack[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const Stack stack{(LdsStackPtr)lds_stack + tid, 256u, lds_depth, ovf ? ovf + (size_t)blockIdx.x * 256u + tid : nullptr, gridDim.x * 256u};
@@ -318,6 +323,26 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
     WfShard *c = &ctr[it % RT_WF_RING].sh[shard];
     if (with_tail && c->tail_mode) return;       // wf_tail_kernel runs this iteration
     const uint32_t n = c->count_in, shard_base = shard * cap;
+    TopLds top{(LdsF4Ptr)0, 0u};
+    if (LT) {       // the top n_top nodes of the tree (breadth-first) behind the stacks, child refs into the image flagged (rt_kernels.h, TopLds)
+        if (n == 0) return;      // block-uniform (this workgroup's shard is empty: nothing to stage the image for)
+        RT_LDS f32x4 *img = (RT_LDS f32x4 *)(lds_stack + lds_depth * 256u);
+        for (uint32_t k = tid; k < 4u * n_top; k += 256u) {
+            const uint32_t node = k >> 2, quarter = k & 3u;
+            float4 v = sc.nodes[4 * (size_t)sc.top_order[node] + quarter];
+            if (quarter == 3u) {
+                const uint32_t *ch = sc.top_child + 4 * node;
+                if (ch[0] < n_top) v.x = __int_as_float((int32_t)(RT_TOP_FLAG | ch[0]));
+                if (ch[1] < n_top) v.y = __int_as_float((int32_t)(RT_TOP_FLAG | ch[1]));
+                if (ch[2] < n_top) v.z = __int_as_float((int32_t)(RT_TOP_FLAG | ch[2]));
+                if (ch[3] < n_top) v.w = __int_as_float((int32_t)(RT_TOP_FLAG | ch[3]));
+            }
+            img[quarter * n_top + node] = f32x4{v.x, v.y, v.z, v.w};
+        }
+        top.img = img; top.count = n_top;
+        __syncthreads();
+    }
+    const int32_t root_ref = LT ? (int32_t)RT_TOP_FLAG : sc.root_ref;     // (the image's node 0 is the root)
     Counters cnt{};
     uint32_t w_next = 0, w_end = 0;
     bool exhausted = n == 0;
@@ -361,7 +386,7 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
                         tv.inv = box_inv(r.d);
                         tv.oi = r.o * tv.inv;
                         tv.sp = 0;
-                        tv.ref = sc.root_ref;
+                        tv.ref = root_ref;
                     }
                 }
             }
@@ -376,7 +401,7 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
             const bool on_node = idx >= 0 && tv.ref >= 0 && tv.ref != RT_BVH_EMPTY;
             phase_count<STATS>(cnt, PH_NODE, on_node);
             RG_BEGIN(RG_NODE);
-            if (on_node) trav_node_step<STATS>(sc, T_MIN, tv, stack, cnt);
+            if (on_node) trav_node_step<STATS, LT>(sc, T_MIN, tv, stack, cnt, top);
             RG_END(RG_NODE);
         }
         if (idx >= 0 && tv.ref < 0 && pend == RT_BVH_EMPTY) { pend = tv.ref; tv.ref = pop_ref(stack, tv.sp); }
@@ -399,7 +424,7 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
     }
     RG_END(RG_TRAV_ALL);
     if (kTimers && !STATS && lane == 0) atomicMax(&stats[RT_STAT_WORDS], (unsigned long long)dbg_turns);   // development builds: longest wave, in loop turns
-    if (STATS || kTimers) flush_counters<STATS>(cnt, 0u, stats);
+    if (STATS || kTimers) flush_counters<STATS>(cnt, 0u, stats, RT_K_TRAVERSE);
 }
 
 /* ------------------------------------------------------------------ shade */
@@ -409,21 +434,73 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
 #ifndef RT_WF_SHADE_WAVES
 #define RT_WF_SHADE_WAVES 1
 #endif
+
+// The bounce of pool entry i (flags = word 3 of its direction quad `d`, 0 for a lane without an entry).  Called by all lanes of
+// the wave (shade_hit shares the wave's noise hits).
+template <bool STATS, int EXT>
+RT_DEV void shade_entry(const DScene &sc, const WfArgs &w, const PathQ &cur, const PathQ &nxt, WfCounters *ctr_it, uint32_t shard, uint32_t i,
+                        float4 d, uint32_t flags, float4 *__restrict__ samples, uint32_t *pixel_rays, Counters &cnt) {
+    const V3 background = v3(w.a.bg[0], w.a.bg[1], w.a.bg[2]);
+    bool survive = false, walk = false;
+    WfPath p;
+    Trav tv;
+    tv.ref = RT_BVH_EMPTY; tv.sp = 0; tv.best.t = 0.0f; tv.best.id = -1; tv.best.slot = 0; tv.floor_id = -1;
+    const bool alive = (flags & WF_ALIVE) != 0u;
+    phase_count<STATS>(cnt, PH_SHADE, alive);
+    bool cont = false;
+    if (alive) {
+        RG_BEGIN(RG_LOAD);
+        const float4 o = cur.ray_o[i], th = cur.thr[i], h = cur.hit[i];
+        const float2 rg = cur.rng[i];
+        p.ps.ray.o = v3(o.x, o.y, o.z); p.ps.ray.d = v3(d.x, d.y, d.z); p.ps.ray.time = o.w;
+        p.ps.throughput = v3(th.x, th.y, th.z); p.item = __float_as_uint(th.w);
+        p.ps.radiance = v3(0.0f, 0.0f, 0.0f);
+        p.ps.depth = (int)(flags & WF_DEPTH_MASK);
+        int px, py;
+        item_pixel(w, p.item, &px, &py, &p.sample);
+        p.pixel = (uint32_t)py * (uint32_t)w.a.width + (uint32_t)px;
+        p.rng.state = ((uint64_t)__float_as_uint(rg.y) << 32) | (uint64_t)__float_as_uint(rg.x);
+        p.rng.inc = (((((uint64_t)p.pixel << 24) ^ (uint64_t)p.sample)) << 1u) | 1u;   // rts::path_rng's stream
+        tv.best.t = h.x; tv.best.id = f2i(h.y); tv.best.slot = f2i(h.z); tv.floor_id = f2i(h.w);
+        RG_END(RG_LOAD);
+        RG_BEGIN(RG_FINISH);
+        finish_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, tv, cnt);
+        RG_END(RG_FINISH);
+    }
+    RG_BEGIN(RG_SHADE_ALL);
+    cont = shade_hit<STATS, EXT>(sc, alive, p.ps, tv.best, background, p.rng, cnt);     // (all lanes: the wave shares its noise hits)
+    RG_END(RG_SHADE_ALL);
+    if (alive) {
+        if (cont && p.ps.depth > 0) survive = true;
+        else {
+            if (cont) end_on_black(p.ps);      // the next call would return black at depth 0 (camera.rs:260)
+            samples[p.item] = make_float4(p.ps.radiance.x, p.ps.radiance.y, p.ps.radiance.z, 0.0f);
+        }
+    }
+    phase_count<STATS>(cnt, PH_BEGIN, survive);
+    if (survive) {
+        if (STATS) { cnt.rays += 1; if (pixel_rays) atomicAdd(&pixel_rays[p.pixel], 1u); }
+        RG_BEGIN(RG_BEGIN_ALL);
+        walk = begin_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt);
+        RG_END(RG_BEGIN_ALL);
+    }
+    RG_BEGIN(RG_STORE);
+    const uint32_t pos = shard * w.cap + wave_append(&ctr_it->sh[shard].n_surv, survive);
+    if (survive) store_entry(nxt, pos, p, tv, walk);
+    RG_END(RG_STORE);
+}
+
 template <bool STATS, int EXT>
 __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene sc_in, WfArgs w, PathQ cur, PathQ nxt, WfCounters *ctr, uint32_t it,
                                                        float4 *__restrict__ samples, unsigned long long *stats, uint32_t *pixel_rays, uint32_t with_tail) {
     DScene sc = sc_in;
     const uint32_t shard = blockIdx.y, off0 = blockIdx.x * blockDim.x;   // block-uniform; grid as in wf_generate_kernel
     uint32_t i = shard * w.cap + off0 + threadIdx.x;
-    WfShard *c = &ctr[it % RT_WF_RING].sh[shard];
+    WfCounters *ctr_it = ctr + (it % RT_WF_RING);
+    WfShard *c = &ctr_it->sh[shard];
     const uint32_t n = c->count_in;
     if (off0 >= n || (with_tail && c->tail_mode)) return;   // block-uniform (tail mode: wf_tail_kernel runs this iteration)
     Counters cnt{};
-    const V3 background = v3(w.a.bg[0], w.a.bg[1], w.a.bg[2]);
-    bool survive = false, walk = false;
-    WfPath p;
-    Trav tv;
-    tv.ref = RT_BVH_EMPTY; tv.sp = 0; tv.best.t = 0.0f; tv.best.id = -1; tv.best.slot = 0; tv.floor_id = -1;
     uint32_t flags = 0;
     float4 d = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #if RT_WF_SORT
@@ -482,50 +559,8 @@ __global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene
 #else
     if (off0 + threadIdx.x < n) { d = cur.ray_d[i]; flags = __float_as_uint(d.w); }
 #endif
-    const bool alive = (flags & WF_ALIVE) != 0u;
-    phase_count<STATS>(cnt, PH_SHADE, alive);
-    bool cont = false;
-    if (alive) {
-        RG_BEGIN(RG_LOAD);
-        const float4 o = cur.ray_o[i], th = cur.thr[i], h = cur.hit[i];
-        const float2 rg = cur.rng[i];
-        p.ps.ray.o = v3(o.x, o.y, o.z); p.ps.ray.d = v3(d.x, d.y, d.z); p.ps.ray.time = o.w;
-        p.ps.throughput = v3(th.x, th.y, th.z); p.item = __float_as_uint(th.w);
-        p.ps.radiance = v3(0.0f, 0.0f, 0.0f);
-        p.ps.depth = (int)(flags & WF_DEPTH_MASK);
-        int px, py;
-        item_pixel(w, p.item, &px, &py, &p.sample);
-        p.pixel = (uint32_t)py * (uint32_t)w.a.width + (uint32_t)px;
-        p.rng.state = ((uint64_t)__float_as_uint(rg.y) << 32) | (uint64_t)__float_as_uint(rg.x);
-        p.rng.inc = (((((uint64_t)p.pixel << 24) ^ (uint64_t)p.sample)) << 1u) | 1u;   // rts::path_rng's stream
-        tv.best.t = h.x; tv.best.id = f2i(h.y); tv.best.slot = f2i(h.z); tv.floor_id = f2i(h.w);
-        RG_END(RG_LOAD);
-        RG_BEGIN(RG_FINISH);
-        finish_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, tv, cnt);
-        RG_END(RG_FINISH);
-    }
-    RG_BEGIN(RG_SHADE_ALL);
-    cont = shade_hit<STATS, EXT>(sc, alive, p.ps, tv.best, background, p.rng, cnt);     // (all lanes: the wave shares its noise hits)
-    RG_END(RG_SHADE_ALL);
-    if (alive) {
-        if (cont && p.ps.depth > 0) survive = true;
-        else {
-            if (cont) end_on_black(p.ps);      // the next call would return black at depth 0 (camera.rs:260)
-            samples[p.item] = make_float4(p.ps.radiance.x, p.ps.radiance.y, p.ps.radiance.z, 0.0f);
-        }
-    }
-    phase_count<STATS>(cnt, PH_BEGIN, survive);
-    if (survive) {
-        if (STATS) { cnt.rays += 1; if (pixel_rays) atomicAdd(&pixel_rays[p.pixel], 1u); }
-        RG_BEGIN(RG_BEGIN_ALL);
-        walk = begin_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt);
-        RG_END(RG_BEGIN_ALL);
-    }
-    RG_BEGIN(RG_STORE);
-    const uint32_t pos = shard * w.cap + wave_append(&c->n_surv, survive);
-    if (survive) store_entry(nxt, pos, p, tv, walk);
-    RG_END(RG_STORE);
-    if (STATS || kTimers) flush_counters<STATS>(cnt, 0u, stats);
+    shade_entry<STATS, EXT>(sc, w, cur, nxt, ctr_it, shard, i, d, flags, samples, pixel_rays, cnt);
+    if (STATS || kTimers) flush_counters<STATS>(cnt, 0u, stats, RT_K_SHADE);
 }
 
 /* ------------------------------------------------------------------ tail */
@@ -687,10 +722,10 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
     if (kTimers && !STATS) {   // development builds: the kernel's own timers apart from the pipeline's (stats + 64)
         const unsigned long long dt = __builtin_readcyclecounter() - tail_t0;
         if (lane == 0) atomicMax(&stats[64 + RT_STAT_WORDS], dt);
-        flush_counters<STATS>(cnt, 0u, stats + 64);
+        flush_counters<STATS>(cnt, 0u, stats + 64, RT_K_TAIL);
         return;
     }
-    if (STATS) flush_counters<STATS>(cnt, 0u, stats);
+    if (STATS) flush_counters<STATS>(cnt, 0u, stats, RT_K_TAIL);
 }
 
 /* ------------------------------------------------------------------ fold */

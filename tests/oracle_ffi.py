@@ -54,6 +54,7 @@ def lib():
         L.orc_resolve_rgb8.argtypes = [fp, C.c_int32, C.c_int32, u8p]; L.orc_resolve_rgb8.restype = None
         L.orc_set_trace.argtypes = [C.c_int32]; L.orc_set_trace.restype = None
         L.orc_bounce.argtypes = [vp, C.c_float * 7, fp, C.c_int32, C.c_float * 22]
+        L.orc_project.argtypes = [C.POINTER(orc_render_params), C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float * 6)]
         L.orc_mat4.argtypes = [C.c_int32, C.c_float * 16, C.c_float * 16]
         _lib = L
     return _lib

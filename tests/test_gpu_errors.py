@@ -266,3 +266,50 @@ def test_resolve_and_first_hit_argument_checks(rt, ctx):
     assert np.all(o == 0.0)
     pid, t, nrm, ff, uv = b.trace_first_hit(np.zeros((7, 0), np.float32))             # no rays: nothing to do, no launch
     assert len(pid) == 0
+
+
+def test_a_boundary_medium_needs_an_isotropic_material_whose_texture_reads_no_uv(rt, ctx):
+    """rt_scene_upload reads the texture of a kind-1 medium's material: that material has to be Isotropic (the texture index of a
+    Metal or Dielectric record is not range-checked and means nothing), and the walk through a checker must find an image below it."""
+    b, flat, params, camera, sampler = ctx
+    scene, *_ = rt.configs.build("SMOKE", image_width=32, samples_per_pixel=4)
+    smoke = scene.flatten()
+    d0 = smoke.desc
+    assert d0.n_media >= 1
+    media = np.ctypeslib.as_array(d0.media, shape=(d0.n_media * 8,)).copy()
+    kinds = media.view(np.int32)[7::8]
+    m = int(np.nonzero(kinds == 1)[0][0])                       # a medium with boundary slots (a Block under Translate / RotateY)
+    mat = int(media.view(np.int32)[m * 8 + 5])
+    mats = np.ctypeslib.as_array(d0.materials, shape=(d0.n_materials * 8,)).copy()
+    texs = np.ctypeslib.as_array(d0.textures, shape=(d0.n_textures * 8,)).copy()
+    assert mats.view(np.int32)[mat * 8] == 4                    # RTG_MAT_ISOTROPIC
+    b.upload_scene(smoke)                                       # as built: accepted
+
+    def with_arrays(materials=None, textures=None, n_textures=None):
+        d = copy_of(d0)
+        if materials is not None:
+            d.materials = materials.ctypes.data_as(rt._ffi.c_float_p)
+        if textures is not None:
+            d.textures = textures.ctypes.data_as(rt._ffi.c_float_p)
+            d.n_textures = n_textures
+        return d
+
+    metal = mats.copy()
+    metal.view(np.int32)[mat * 8] = 1                           # RTG_MAT_METAL, and a texture word that points nowhere
+    metal.view(np.int32)[mat * 8 + 1] = 0x7fffff00
+    st, msg = status_and_text(b, b._L.rt_scene_upload(b._h, C.byref(with_arrays(materials=metal))))
+    assert st == RT_E_INVALID and "not Isotropic" in msg, (st, msg)
+    # a checker over (solid, image) as the phase function's texture: refused like a bare image
+    nt = d0.n_textures
+    more = np.zeros((nt + 2) * 8, np.float32)
+    more[:nt * 8] = texs
+    more.view(np.int32)[nt * 8:nt * 8 + 8] = [3, 0, 0, 0, -1, 0, 0, 0]                       # RTG_TEX_IMAGE without texels (cyan)
+    more.view(np.int32)[(nt + 1) * 8:(nt + 1) * 8 + 8] = [1, 0, 0, 0, 0, nt, 0, 0]           # RTG_TEX_CHECKER: odd = texture 0, even = the image
+    more[(nt + 1) * 8 + 6] = 4.0
+    iso = mats.copy()
+    iso.view(np.int32)[mat * 8 + 1] = nt + 1
+    st, msg = status_and_text(b, b._L.rt_scene_upload(b._h, C.byref(with_arrays(materials=iso, textures=more, n_textures=nt + 2))))
+    assert st == RT_E_UNSUPPORTED_PRIMITIVE and "image texture" in msg, (st, msg)
+    b.upload_scene(flat)                                        # the context is still usable
+    b.upload_sampler(sampler)
+    assert np.isfinite(b.render(params, camera)[0]).all()

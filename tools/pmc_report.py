@@ -18,10 +18,17 @@ out = {"workload": b["config"]["workload"], "rays": rays, "kernels": {}}
 for k, a in agg.items():
     d = {"dispatches": calls[k], "dispatch": meta[k], "counters": dict(a),
          "valu_lane_slots_per_ray": a["SQ_INSTS_VALU"] * 64 / rays,
-         "valu_pipe_note": "valu_pipe_busy_pct assumes 4 cycles per wave64 VALU op; the guide measures 2 (SIMD-32), so halve it",
+         "valu_pipe_note": "valu_pipe_busy_pct prices a wave64 VALU op at the 2.2 cycles a SIMD issues one in with several waves resident "
+                           "(tools/valu_issue_bench.hip on this box: 2.17 at 8 waves, 2.44 at 4, 4.5 for a wave that is alone; the guide: 2); "
+                           "valu_pipe_busy_pct_at_4_cycles is round 2's figure (one wave's own issue rate)",
          "lane_utilisation_pct": 100 * a["SQ_THREAD_CYCLES_VALU"] / (a["SQ_ACTIVE_INST_VALU"] * 64) if a["SQ_ACTIVE_INST_VALU"] else None,
          # SQ_BUSY_CYCLES is summed over 32 shader engines; 1024 SIMDs issue one wave64 VALU op per 4 cycles
-         "valu_pipe_busy_pct": 100 * a["SQ_INSTS_VALU"] * 4 / (a["SQ_BUSY_CYCLES"] / 32 * 1024) if a["SQ_BUSY_CYCLES"] else None,
+         "valu_pipe_busy_pct": 100 * a["SQ_INSTS_VALU"] * 2.2 / (a["SQ_BUSY_CYCLES"] / 32 * 1024) if a["SQ_BUSY_CYCLES"] else None,
+         "valu_pipe_busy_pct_at_4_cycles": 100 * a["SQ_INSTS_VALU"] * 4 / (a["SQ_BUSY_CYCLES"] / 32 * 1024) if a["SQ_BUSY_CYCLES"] else None,
+         # what a wave's cycles go to (quad-cycles; the three are disjoint and add up to SQ_WAVE_CYCLES): parked at s_waitcnt
+         # (memory, LDS), stalled at issue, issuing
+         "wave_cycles_waitcnt_pct": 100 * a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"] if a["SQ_WAVE_CYCLES"] and "SQ_WAIT_ANY" in a else None,
+         "wave_cycles_issuing_pct": 100 * a["SQ_ACTIVE_INST_ANY"] / a["SQ_WAVE_CYCLES"] if a["SQ_WAVE_CYCLES"] and "SQ_ACTIVE_INST_ANY" in a else None,
          "waves_per_simd_avg": a["SQ_WAVE_CYCLES"] * 4 / (a["SQ_BUSY_CYCLES"] / 32 * 1024) if a["SQ_BUSY_CYCLES"] else None,
          "wait_inst_share_pct": 100 * a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"] if a["SQ_WAVE_CYCLES"] else None,
          "busy_ms": a["SQ_BUSY_CYCLES"] / 32 / 2.4e6,
