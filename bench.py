@@ -163,25 +163,38 @@ class Bench:
             dist.barrier()
         torch.cuda.synchronize()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        # N > 1: the exchange of frame k runs on a stream of its own, behind that frame's render, while frame k + 1 renders into
-        # the other of two accumulation buffers (the collective is a copy over xGMI, the render is compute: they overlap);
-        # every reduce is inside the timed region (barrier + device synchronize below)
-        accs = [acc, torch.zeros_like(acc)] if self.comm is not None else [acc]
+        # Frames in flight (--frames, default 2): frame k is ordered on stream k % 2 and accumulates into buffer k % 2, so the
+        # last launches of a frame (a few hundred waves of the tail kernel) run beside the first ones of the next; rt_render
+        # keeps a workspace per frame in flight.  Every frame is whole inside the timed region (device synchronize below) and
+        # is checked against the counting run's image afterwards.  --frames 1: one stream, one buffer, one frame at a time.
+        # N > 1: the exchange of frame k runs on a stream of its own, behind that frame's render (the collective is a copy over
+        # xGMI, the render is compute: they overlap); every reduce is inside the timed region (barrier + synchronize below)
+        n_fl = 2 if (self.comm is not None or args.frames > 1) else 1
+        accs = [acc] + [torch.zeros_like(acc) for _ in range(n_fl - 1)]
+        streams = [self.stream] + [torch.cuda.Stream(device=dev) for _ in range(n_fl - 1)] if args.frames > 1 else [self.stream] * n_fl
         comm_stream = torch.cuda.Stream(device=dev) if self.comm is not None else None
         rendered = [torch.cuda.Event() for _ in accs]
         reduced = [torch.cuda.Event() for _ in accs]
+        for k in range(min(warmup, 2) * n_fl if n_fl > 1 else 0):     # untimed: the second workspace and its streams come into being
+            with torch.cuda.stream(streams[k % n_fl]):
+                accs[k % n_fl].zero_()
+                gpu.render_device(params, camera, accs[k % n_fl].data_ptr(), streams[k % n_fl].cuda_stream, spp_begin=spp_begin, spp_count=spp_count)
+        if dist is not None:
+            dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(steps):
-            b = k % len(accs)
-            if self.comm is not None and k >= len(accs):
-                self.stream.wait_event(reduced[b])        # the reduce of the frame that used this buffer last has read it
-            accs[b].zero_()
-            ev[k][0].record(self.stream)
-            gpu.render_device(params, camera, accs[b].data_ptr(), sptr, spp_begin=spp_begin, spp_count=spp_count)
-            ev[k][1].record(self.stream)
+            b = k % n_fl
+            s_k = streams[b]
+            if self.comm is not None and k >= n_fl:
+                s_k.wait_event(reduced[b])        # the reduce of the frame that used this buffer last has read it
+            with torch.cuda.stream(s_k):
+                accs[b].zero_()
+            ev[k][0].record(s_k)
+            gpu.render_device(params, camera, accs[b].data_ptr(), s_k.cuda_stream, spp_begin=spp_begin, spp_count=spp_count)
+            ev[k][1].record(s_k)
             if self.comm is not None:
-                rendered[b].record(self.stream)
+                rendered[b].record(s_k)
                 comm_stream.wait_event(rendered[b])
                 self.comm.reduce_to_root(accs[b].data_ptr(), accs[b].numel(), 0, comm_stream.cuda_stream)
                 reduced[b].record(comm_stream)
@@ -193,13 +206,16 @@ class Bench:
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        frame_ms = sum(a.elapsed_time(b) for a, b in ev) / steps           # start to end of a frame on its stream
+        # device time per frame: first frame's start to the last end, over the frames (= frame_ms with one frame in flight)
+        kernel_ms = max(ev[0][0].elapsed_time(e[1]) for e in ev[-n_fl:]) / steps if n_fl > 1 else frame_ms
         if self.rank != 0:
             return None
         # sanity: the timed kernels' image equals the counting variant's, bit for bit (world 1: nothing was reduced into it)
         if self.world == 1:
-            a, b = acc.cpu().numpy(), count_img.cpu().numpy()
-            assert np.array_equal(np.nan_to_num(a), np.nan_to_num(b)), "timed kernel and counting kernel disagree"
+            b = count_img.cpu().numpy()
+            for a in accs[:min(steps, n_fl)]:
+                assert np.array_equal(np.nan_to_num(a.cpu().numpy()), np.nan_to_num(b)), "timed kernel and counting kernel disagree"
         del acc, accs, count_img
         flops = algorithmic_flops(st)
         # HBM-side bytes per step: PMC passes of this very workload (tools/pmc.sh), committed under profiles/
@@ -245,10 +261,11 @@ class Bench:
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
                          "kernel": "one rt_render call = the wavefront pipeline (rtk::wf_generate_kernel, wf_traverse_kernel, "
                                    "wf_shade_kernel, wf_tail_kernel, wf_fold_kernel)",
-                         "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
+                         "kernel_ms": kernel_ms, "frame_ms": frame_ms, "frames_in_flight": n_fl if args.frames > 1 else 1,
+                         "algorithmic_flops_per_launch": flops,
                          "kernels": per_kernel, "kernels_busy_from": busy_src,
                          "note": "no dense contraction -> FP32 vector roofline (SURVEY.md 8d); flops = work counters x per-unit constants; "
-                                 "kernel_ms = HIP events on the caller's stream around the call (the pipelines' streams fork from and join it); "
+                                 "kernel_ms = device time per call: HIP events on the caller's streams from the first call's start to the last one's end, over the calls (the pipelines' streams fork from and join the caller's; with two frames in flight the end of one call runs beside the start of the next, frame_ms = start to end of one call); "
                                  "kernels = per kernel: counters of that kernel (rt_last_kernel_stats) x the same constants over its busy time per frame in the committed kernel trace; "
                                  "traffic = FETCH_SIZE*2 + WRITE_SIZE bytes per step over all kernels, from " + (traffic_src or "n/a")},
         }
@@ -298,6 +315,7 @@ def main():
     ap.add_argument("--workload", default="C1")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--frames", type=int, default=2, choices=[1, 2], help="frames in flight: 2 = consecutive frames on two streams and two buffers (default), 1 = one at a time")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="skip the C2 / C3 / C4 sub-workloads of the default run")
     ap.add_argument("--sub", default=None, help="comma-separated sub-workloads instead of C2,C3,C4")
@@ -318,6 +336,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    if args.frames > 1:
+        # two frames in flight = two caller streams + two pipeline streams per frame: with HIP's default of 4 hardware queues
+        # per process they share queues and run one after the other (profiles/r3/ab_frames_in_flight.txt); read at HIP start-up
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import rtiow_loader
     rt = rtiow_loader.load()

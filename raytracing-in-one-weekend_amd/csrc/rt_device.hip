@@ -23,6 +23,27 @@
 
 using namespace rtk;
 
+constexpr int kMaxPipes = 4;
+constexpr int kFrames = 2;     // renders in flight per context: each has a workspace of its own
+
+// Workspace of one render in flight.  rt_render returns once a frame's last kernels are queued; the frame's workspace is
+// taken again by the render after next, which first waits for `done` (settle()).
+struct WfSpace {
+    void *pool = nullptr;      size_t pool_entries = 0;         // 2 buffers x entries x 72 B per pipeline
+    float4 *samples = nullptr; size_t samples_entries = 0;
+    WfCounters *ctr = nullptr;                                  // per pipeline: ring + status words behind it
+    StackEntry *ovf = nullptr; size_t ovf_entries = 0;          // traversal stack overflow (entries beyond the LDS part)
+    uint32_t *host_status = nullptr;                            // pinned, per pipeline 2 x 4 words
+    hipStream_t stream[kMaxPipes] = {};                         // one per pipeline
+    hipEvent_t event[kMaxPipes][2] = {};
+    hipEvent_t fork = nullptr, join[kMaxPipes] = {}, done = nullptr;
+    // the frame in flight: `done` follows its fold on the caller's stream; the pipelines whose last iterations were queued
+    // without waiting for their status leave it in host_status[8 q + 4 final_at[q]], to be looked at when the frame has settled
+    bool in_flight = false;
+    int final_at[kMaxPipes] = {-1, -1, -1, -1};                 // -1: the host has seen this pipeline drained
+    uint32_t final_items[kMaxPipes] = {};
+};
+
 struct rt_ctx {
     int device = 0;
     std::string error;
@@ -40,16 +61,9 @@ struct rt_ctx {
     rt_stats kernel_stats[RT_K_COUNT] = {}; // ... of the last render with collect_stats (rt_last_kernel_stats)
     bool have_kernel_stats = false;
     hipDeviceProp_t prop{};
-    // wavefront workspace (grown on demand, kept until rt_destroy)
-    void *wf_pool = nullptr;      size_t wf_pool_entries = 0;   // 2 buffers x entries x 72 B
-    float4 *wf_samples = nullptr; size_t wf_samples_entries = 0;
-    bool wf_ready = false;                                      // counters, pinned status words, streams and events below exist
-    WfCounters *wf_ctr = nullptr;                               // ring + status words behind it
-    StackEntry *wf_ovf = nullptr;  size_t wf_ovf_entries = 0;      // traversal stack overflow (entries beyond the LDS part)
-    uint32_t *wf_host_status = nullptr;                         // pinned, per pipeline 2 x 4 words
-    hipStream_t wf_stream[4] = {};                              // one per pipeline (render_wavefront)
-    hipEvent_t wf_event[4][2] = {};
-    hipEvent_t wf_fork = nullptr, wf_join[4] = {};
+    // wavefront workspaces (grown on demand, kept until rt_destroy): one per render in flight (render_wavefront)
+    WfSpace wf[kFrames];
+    int wf_last = 0;                                            // the workspace the last render used
     char *noalloc_scratch = nullptr;   // = g_noalloc_ptr[device]
 };
 
@@ -163,14 +177,13 @@ template <bool STATS> WfKernels<STATS> wf_kernels(int features, bool tree_has_xf
     }
 }
 
-constexpr int kMaxPipes = 4;
 constexpr uint32_t kMaxStackDepth = 256;   // traversal stack entries; beyond the LDS part they live in HBM
 constexpr size_t kMaxTopNodes = 1024;      // breadth-first table of the tree's top (DScene::top_order): more than any launch stages
 constexpr size_t kEntryBytes = 72;   // rt_wavefront.h: 4 float4 + 1 float2 per pool entry
 
-PathQ pool_buffer(rt_ctx *ctx, int which) {
-    const size_t n = ctx->wf_pool_entries;
-    char *base = static_cast<char *>(ctx->wf_pool) + (size_t)which * kEntryBytes * n;
+PathQ pool_buffer(const WfSpace &S, int which) {
+    const size_t n = S.pool_entries;
+    char *base = static_cast<char *>(S.pool) + (size_t)which * kEntryBytes * n;
     PathQ q;
     q.ray_o = reinterpret_cast<float4 *>(base); q.ray_d = q.ray_o + n; q.thr = q.ray_d + n; q.hit = q.thr + n;
     q.rng = reinterpret_cast<float2 *>(q.hit + n);
@@ -197,6 +210,28 @@ uint32_t tile_stride_for(uint32_t n) {
     auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
     while (s > 1 && gcd(s, n) != 1) --s;
     return (uint32_t)s;
+}
+
+// Wait for the frame that used this workspace last.  Pipelines whose last iterations were queued without waiting for their
+// status (render_wavefront) must have ended with an empty pool and every item handed out: the bound on their iterations says
+// so, and this is where a violation of it would be reported.
+int settle(rt_ctx *ctx, WfSpace &S) {
+    if (!S.in_flight) return RT_OK;
+    S.in_flight = false;
+    HIP_TRY(ctx, hipEventSynchronize(S.done));
+    for (int q = 0; q < kMaxPipes; ++q) {
+        if (S.final_at[q] < 0) continue;
+        const uint32_t *hs = S.host_status + 8 * q + 4 * S.final_at[q];
+        S.final_at[q] = -1;
+        if (hs[0] != 0u || hs[1] != S.final_items[q])
+            return fail(ctx, RT_E_HIP, "the previous render ended with %u paths alive and %u of %u items handed out (pipeline %d)", hs[0], hs[1], S.final_items[q], q);
+    }
+    return RT_OK;
+}
+int settle_all(rt_ctx *ctx) {
+    int rc = RT_OK;
+    for (WfSpace &S : ctx->wf) { const int r = settle(ctx, S); if (rc == RT_OK) rc = r; }
+    return rc;
 }
 
 // The streaming pipeline of rt_wavefront.h for one rt_render call.  Samples are rendered in batches
@@ -226,49 +261,43 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     size_t pool_want = ((size_t)1 << env_size("RT_WF_POOL_LOG2", 23, 14, 26)) / (size_t)n_pipes;   // per pipeline
     pool_want = pool_want / shard_q * shard_q;
     if (pool_want < shard_q) pool_want = shard_q;
-    // workspace
-    if (ctx->wf_samples_entries < need_samples) {
-        if (ctx->wf_samples) { (void)hipStreamSynchronize(stream); (void)hipFree(ctx->wf_samples); ctx->wf_samples = nullptr; ctx->wf_samples_entries = 0; }
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->wf_samples, need_samples * 16));
-        ctx->wf_samples_entries = need_samples;
+    // workspace: the one the last render did not use, once the frame that used it before has settled.  With two of them a
+    // frame's last launches (C1 at 10 spp: 0.6 of its 2.5 ms are the tail kernel on a few hundred waves) run beside the next
+    // frame's first ones when the caller orders the two on different streams; RT_WF_FRAMES=1 keeps one workspace, and a render
+    // that reads counters back (collect_stats, the timers of a development build) has the device to itself.
+    const int n_frames = (STATS || kTimers) ? 1 : (int)env_size("RT_WF_FRAMES", kFrames, 1, kFrames);
+    if (n_frames == 1) { const int rc = settle_all(ctx); if (rc != RT_OK) return rc; }
+    ctx->wf_last = n_frames == 1 ? 0 : (ctx->wf_last + 1) % n_frames;
+    WfSpace &S = ctx->wf[ctx->wf_last];
+    { const int rc = settle(ctx, S); if (rc != RT_OK) return rc; }
+    if (S.samples_entries < need_samples) {
+        if (S.samples) { (void)hipDeviceSynchronize(); (void)hipFree(S.samples); S.samples = nullptr; S.samples_entries = 0; }
+        HIP_TRY(ctx, hipMalloc((void **)&S.samples, need_samples * 16));
+        S.samples_entries = need_samples;
     }
     const size_t per_pipe_items = (need_samples + n_pipes - 1) / n_pipes;
     size_t pool = per_pipe_items < pool_want ? (per_pipe_items + shard_q - 1) / shard_q * shard_q : pool_want;
-    if (ctx->wf_pool_entries < pool) {
-        if (ctx->wf_pool) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->wf_pool); ctx->wf_pool = nullptr; ctx->wf_pool_entries = 0; }
-        HIP_TRY(ctx, hipMalloc(&ctx->wf_pool, pool * 2 * kEntryBytes * kMaxPipes));
-        ctx->wf_pool_entries = pool;
+    if (S.pool_entries < pool) {
+        if (S.pool) { (void)hipDeviceSynchronize(); (void)hipFree(S.pool); S.pool = nullptr; S.pool_entries = 0; }
+        HIP_TRY(ctx, hipMalloc(&S.pool, pool * 2 * kEntryBytes * kMaxPipes));
+        S.pool_entries = pool;
     }
-    if (!ctx->wf_ready) {   // one-time set-up; on a failure everything made so far is released again, so the next call starts afresh
-        WfCounters *ctr = nullptr;
-        uint32_t *host_status = nullptr;
-        hipStream_t streams[kMaxPipes] = {};
-        hipEvent_t events[kMaxPipes][2] = {}, join[kMaxPipes] = {}, fork = nullptr;
-        hipError_t e = hipMalloc((void **)&ctr, kMaxPipes * (RT_WF_RING + 1) * sizeof(WfCounters));   // per pipe: ring + one block for the status words
-        if (e == hipSuccess) e = hipHostMalloc((void **)&host_status, kMaxPipes * 2 * 4 * sizeof(uint32_t), hipHostMallocDefault);
-        for (int q = 0; q < kMaxPipes && e == hipSuccess; ++q) {
-            e = hipStreamCreateWithFlags(&streams[q], hipStreamNonBlocking);
-            for (hipEvent_t &ev : events[q]) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&join[q], hipEventDisableTiming);
+    // counters, status words, streams and events: made when first needed and kept (what exists after a failure is used by the
+    // next call or released by rt_destroy).  (Measured and dropped, profiles/r3/ab_frames_in_flight.txt: a second stream of the
+    // highest priority per pipeline for the iterations after the host has seen the pool in tail mode — with two frames in flight
+    // 6 % slower than without, and a hang with three pipelines once such streams shared a hardware queue.)
+    {
+        hipError_t e = hipSuccess;
+        if (!S.ctr) e = hipMalloc((void **)&S.ctr, kMaxPipes * (RT_WF_RING + 1) * sizeof(WfCounters));   // per pipe: ring + one block for the status words
+        if (e == hipSuccess && !S.host_status) e = hipHostMalloc((void **)&S.host_status, kMaxPipes * 2 * 4 * sizeof(uint32_t), hipHostMallocDefault);
+        if (e == hipSuccess && !S.fork) e = hipEventCreateWithFlags(&S.fork, hipEventDisableTiming);
+        if (e == hipSuccess && !S.done) e = hipEventCreateWithFlags(&S.done, hipEventDisableTiming);
+        for (int q = 0; q < n_pipes && e == hipSuccess; ++q) {
+            if (!S.stream[q]) e = hipStreamCreateWithFlags(&S.stream[q], hipStreamNonBlocking);
+            for (hipEvent_t &ev : S.event[q]) if (e == hipSuccess && !ev) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess && !S.join[q]) e = hipEventCreateWithFlags(&S.join[q], hipEventDisableTiming);
         }
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
-        if (e != hipSuccess) {
-            if (ctr) (void)hipFree(ctr);
-            if (host_status) (void)hipHostFree(host_status);
-            for (int q = 0; q < kMaxPipes; ++q) {
-                if (streams[q]) (void)hipStreamDestroy(streams[q]);
-                for (hipEvent_t ev : events[q]) if (ev) (void)hipEventDestroy(ev);
-                if (join[q]) (void)hipEventDestroy(join[q]);
-            }
-            if (fork) (void)hipEventDestroy(fork);
-            return fail(ctx, e == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP, "render workspace set-up failed: %s", hipGetErrorString(e));
-        }
-        ctx->wf_ctr = ctr; ctx->wf_host_status = host_status; ctx->wf_fork = fork;
-        for (int q = 0; q < kMaxPipes; ++q) {
-            ctx->wf_stream[q] = streams[q]; ctx->wf_join[q] = join[q];
-            ctx->wf_event[q][0] = events[q][0]; ctx->wf_event[q][1] = events[q][1];
-        }
-        ctx->wf_ready = true;
+        if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP, "render workspace set-up failed: %s", hipGetErrorString(e));
     }
     // traversal stack: the first lds_depth entries of every lane in LDS, the (rarely reached) rest in HBM
     // The top of the tree (breadth-first) in LDS behind the stacks (rt_kernels.h, TopLds).  Measured (profiles/r3/
@@ -302,10 +331,10 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     if (per_cu < 1) per_cu = 1;
     const unsigned trav_blocks = ((unsigned)(per_cu * ctx->prop.multiProcessorCount) + RT_WF_SHARDS - 1) / RT_WF_SHARDS * RT_WF_SHARDS;
     const size_t ovf_per_pipe = (size_t)(ctx->stack_depth - lds_depth) * trav_blocks * 256;
-    if (ovf_per_pipe * kMaxPipes > ctx->wf_ovf_entries) {
-        if (ctx->wf_ovf) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->wf_ovf); ctx->wf_ovf = nullptr; ctx->wf_ovf_entries = 0; }
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->wf_ovf, ovf_per_pipe * kMaxPipes * sizeof(StackEntry)));
-        ctx->wf_ovf_entries = ovf_per_pipe * kMaxPipes;
+    if (ovf_per_pipe * kMaxPipes > S.ovf_entries) {
+        if (S.ovf) { (void)hipDeviceSynchronize(); (void)hipFree(S.ovf); S.ovf = nullptr; S.ovf_entries = 0; }
+        HIP_TRY(ctx, hipMalloc((void **)&S.ovf, ovf_per_pipe * kMaxPipes * sizeof(StackEntry)));
+        S.ovf_entries = ovf_per_pipe * kMaxPipes;
     }
     const bool debug = getenv("RT_DEBUG") != nullptr;
     unsigned long long *d_stats = (STATS || kTimers) ? ctx->d_stats : nullptr;
@@ -330,6 +359,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     const size_t tail_lds = (size_t)lds_depth * tail_blk * sizeof(StackEntry);
     const int tail_group = (int)env_size("RT_WF_TAIL_GROUP", 2, 1, 16);   // iterations enqueued at a time once every item is out
     const uint32_t tail_regroup = (uint32_t)env_size("RT_WF_TAIL_REGROUP", 1, 0, 1);   // survivors of a tail iteration are grouped by the slot they last hit
+    const bool hand_off = !STATS && !kTimers && env_size("RT_WF_HAND_OFF", 1, 0, 1) != 0;   // return without waiting for the last status (0: wait, as before)
     const uint32_t tail_hint = (uint32_t)env_size("RT_WF_TAIL_HINT", 1, 0, 1);         // a bounce's walk starts with the sphere the path has just hit as a candidate
 
     struct Pipe {
@@ -346,15 +376,16 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
         bool items_out;           // the host has seen a status with every item handed out: the pool only shrinks from there
         bool drained;
         uint32_t known_out;       // items handed out as of the last status the host has seen
+        uint32_t tail_from;       // every iteration from this one on was enqueued as a possible tail iteration (0: none yet)
     } pipe[kMaxPipes];
     for (int q = 0; q < n_pipes; ++q) {
         Pipe &P = pipe[q];
-        P.s = n_pipes == 1 ? stream : ctx->wf_stream[q];
-        P.Q[0] = pool_buffer(ctx, 2 * q); P.Q[1] = pool_buffer(ctx, 2 * q + 1);
-        P.ctr = ctx->wf_ctr + (size_t)q * (RT_WF_RING + 1);
+        P.s = n_pipes == 1 ? stream : S.stream[q];
+        P.Q[0] = pool_buffer(S, 2 * q); P.Q[1] = pool_buffer(S, 2 * q + 1);
+        P.ctr = S.ctr + (size_t)q * (RT_WF_RING + 1);
         P.d_status = reinterpret_cast<uint32_t *>(P.ctr + RT_WF_RING);
-        P.h_status = ctx->wf_host_status + (size_t)q * 8;
-        P.ovf = ovf_per_pipe ? ctx->wf_ovf + (size_t)q * ovf_per_pipe : nullptr;
+        P.h_status = S.host_status + (size_t)q * 8;
+        P.ovf = ovf_per_pipe ? S.ovf + (size_t)q * ovf_per_pipe : nullptr;
         P.w = WfArgs{};
         P.w.a = a;
         P.w.tiles_x = tiles_x; P.w.n_tiles = n_tiles;
@@ -362,9 +393,10 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     }
     for (int32_t s0 = 0; s0 < a.spp_count; s0 += (int32_t)spp_batch_max) {
         const uint32_t spp_batch = (uint32_t)((size_t)(a.spp_count - s0) < spp_batch_max ? (size_t)(a.spp_count - s0) : spp_batch_max);
+        const bool last_batch = (size_t)s0 + spp_batch >= (size_t)a.spp_count;
         if (n_pipes > 1) {   // the pipelines start after whatever the caller queued before this call
-            HIP_TRY(ctx, hipEventRecord(ctx->wf_fork, stream));
-            for (int q = 0; q < n_pipes; ++q) HIP_TRY(ctx, hipStreamWaitEvent(pipe[q].s, ctx->wf_fork, 0));
+            HIP_TRY(ctx, hipEventRecord(S.fork, stream));
+            for (int q = 0; q < n_pipes; ++q) HIP_TRY(ctx, hipStreamWaitEvent(pipe[q].s, S.fork, 0));
         }
         for (int q = 0; q < n_pipes; ++q) {
             Pipe &P = pipe[q];
@@ -388,7 +420,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             if (env_size("RT_WF_SAMPLE_MAJOR", balanced ? 1 : 0, 0, 1)) magic_div(w.tiles_pipe, &w.tp_m, &w.tp_k);
             w.n_items = w.tiles_pipe * spp_batch * 64u;
             const size_t items_up = ((size_t)w.n_items + shard_q - 1) / shard_q * shard_q;
-            w.pool = (uint32_t)(items_up < ctx->wf_pool_entries ? items_up : ctx->wf_pool_entries);
+            w.pool = (uint32_t)(items_up < S.pool_entries ? items_up : S.pool_entries);
             if (w.pool > pool_want) w.pool = (uint32_t)pool_want;
             w.cap = w.pool / RT_WF_SHARDS;
             P.chunks = w.cap / 256u;
@@ -396,10 +428,10 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             P.items_out = w.n_items <= w.pool;
             P.trav_blocks = trav_blocks;
             HIP_TRY(ctx, hipMemsetAsync(P.ctr, 0, (RT_WF_RING + 1) * sizeof(WfCounters), P.s));
-            P.it = 0; P.groups = 0; P.drained = false; P.known_out = 0;
+            P.it = 0; P.groups = 0; P.drained = false; P.known_out = 0; P.tail_from = 0;
             P.it_end = P.items_out ? (uint32_t)(a.max_depth > 0 ? a.max_depth : 0) + 1u : 0xffffffffu;
             hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, w, P.Q[1], P.ctr, P.it,
-                               ctx->wf_samples, P.d_status, d_stats, d_rays);
+                               S.samples, P.d_status, d_stats, d_rays);
         }
         auto enqueue_iteration = [&](Pipe &P) {
             if (P.items_out && P.it >= P.it_end) return;   // every path has run out of depth by then: nothing left to enqueue
@@ -412,15 +444,16 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             // nothing to do still has to wait for registers and LDS to come free, which stalls its pipeline)
             const bool near_end = (uint64_t)(P.w.n_items - P.known_out) <= 8ull * (uint64_t)P.w.pool;
             const uint32_t with_tail = tail_max && (P.items_out || (near_end && (int)(it % (uint32_t)tail_every) == tail_every - 1)) ? 1u : 0u;
+            if (with_tail && P.items_out) { if (!P.tail_from) P.tail_from = it; } else P.tail_from = 0;
             if (has_bvh) hipLaunchKernelGGL(trav_kernel, dim3(P.trav_blocks), dim3(256), lds, P.s, ctx->sc, cur, P.ctr, it, P.w.cap,
                                             lds_depth, P.ovf, d_stats, with_tail, n_top);
             hipLaunchKernelGGL(K.shade, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
-                               ctx->wf_samples, d_stats, d_rays, with_tail);
+                               S.samples, d_stats, d_rays, with_tail);
             if (with_tail)
                 hipLaunchKernelGGL(tail_kernel, dim3(tail_waves * 64u / tail_blk), dim3(tail_blk), tail_lds, P.s, ctx->sc, P.w, cur, nxt, P.ctr, it,
-                                   tail_bounces, tail_bounces2, tail_set, tail_thin, lds_depth, P.ovf, ctx->wf_samples, d_stats, d_rays, tail_regroup, tail_hint);
+                                   tail_bounces, tail_bounces2, tail_set, tail_thin, lds_depth, P.ovf, S.samples, d_stats, d_rays, tail_regroup, tail_hint);
             hipLaunchKernelGGL(K.generate, dim3(P.chunks, RT_WF_SHARDS), dim3(256), 0, P.s, ctx->sc, P.w, nxt, P.ctr, it,
-                               ctx->wf_samples, P.d_status, d_stats, d_rays);
+                               S.samples, P.d_status, d_stats, d_rays);
         };
         // groups of 8 iterations while items are handed out; 2 in the tail, where what is enqueued after the pool has drained
         // (the host learns of it a group late) is pure waste
@@ -436,7 +469,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                 if (P.drained) continue;
                 const uint32_t group = P.groups;
                 if (group >= 2) {   // look at the status copied after group - 2
-                    HIP_TRY(ctx, hipEventSynchronize(ctx->wf_event[q][group & 1]));
+                    HIP_TRY(ctx, hipEventSynchronize(S.event[q][group & 1]));
                     const uint32_t *hs = P.h_status + 4 * (group & 1);
                     if (debug) fprintf(stderr, "[rt] pipe %d after iteration %u: %u paths live, %u of %u items out\n", q, hs[2], hs[0], hs[1], P.w.n_items);
                     if (hs[0] == 0u && hs[1] == P.w.n_items) { P.drained = true; --live; continue; }
@@ -452,13 +485,15 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                         P.chunks = need < 1u ? 1u : (need < P.w.cap / 256u ? need : P.w.cap / 256u);
                         const unsigned tb = P.chunks * RT_WF_SHARDS;
                         P.trav_blocks = tb < trav_blocks ? tb : trav_blocks;
-                        if (tail_max && hs[0] <= tail_max) {   // tail mode (the pool only shrinks): every iteration enqueued from here on is
-                            // a tail iteration; the first of them takes at least min(tail_bounces, tail_bounces2) units of depth off
-                            // every path (it may be the first tail iteration or a later one), each one after it tail_bounces2: that
-                            // many more iterations empty the pool whatever the scene (Book-1 at depth 50: 4 + 64 bounces = 2)
+                        if (tail_max && hs[0] <= tail_max) {   // tail mode (the pool only shrinks): iteration hs[2], which this status
+                            // describes, and every one after it is a tail iteration if it was (or will be) enqueued as one.  The first
+                            // of them takes at least min(tail_bounces, tail_bounces2) units of depth off every path (it may be the first
+                            // tail iteration or a later one), each one after it tail_bounces2: after that many the pool is empty
+                            // whatever the scene (Book-1 at depth 50: 4 + 64 bounces = 2 iterations, usually enqueued already)
                             const uint32_t depth = (uint32_t)(a.max_depth > 0 ? a.max_depth : 0);
                             const uint32_t first = tail_bounces < tail_bounces2 ? tail_bounces : tail_bounces2;
-                            const uint32_t end = P.it + 1u + (depth > first ? (depth - first + tail_bounces2 - 1u) / tail_bounces2 : 0u);
+                            const uint32_t from = P.tail_from == 0u ? P.it + 1u : (hs[2] > P.tail_from ? hs[2] : P.tail_from);
+                            const uint32_t end = from + (depth > first ? (depth - first + tail_bounces2 - 1u) / tail_bounces2 : 0u);
                             if (end < P.it_end) P.it_end = end;
                         }
                         // (belt and braces: everything enqueued has run and something is still alive — go on one iteration at a time)
@@ -469,19 +504,27 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
                     for (int k = 0, gsize = group_size(P); k < gsize; ++k) enqueue_iteration(P);
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipMemcpyAsync(P.h_status + 4 * (group & 1), P.d_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, P.s));
-                HIP_TRY(ctx, hipEventRecord(ctx->wf_event[q][group & 1], P.s));
+                HIP_TRY(ctx, hipEventRecord(S.event[q][group & 1], P.s));
                 ++P.groups;
+                // everything this pipeline can need is queued (every item is out and no path has depth left after iteration
+                // it_end): the host does not wait for the status that says so — settle() reads it when the workspace is next used
+                if (hand_off && last_batch && P.items_out && P.it >= P.it_end) {
+                    S.final_at[q] = (int)(group & 1); S.final_items[q] = P.w.n_items;
+                    P.drained = true; --live;
+                }
             }
         }
         if (n_pipes > 1)     // the fold (and whatever the caller queues next) waits for every pipeline
             for (int q = 0; q < n_pipes; ++q) {
-                HIP_TRY(ctx, hipEventRecord(ctx->wf_join[q], pipe[q].s));
-                HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->wf_join[q], 0));
+                HIP_TRY(ctx, hipEventRecord(S.join[q], pipe[q].s));
+                HIP_TRY(ctx, hipStreamWaitEvent(stream, S.join[q], 0));
             }
         WfArgs wf = pipe[0].w;
-        hipLaunchKernelGGL(wf_fold_kernel, dim3((n_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, wf, ctx->wf_samples, d_out);
+        hipLaunchKernelGGL(wf_fold_kernel, dim3((n_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, wf, S.samples, d_out);
         HIP_TRY(ctx, hipGetLastError());
     }
+    HIP_TRY(ctx, hipEventRecord(S.done, stream));
+    S.in_flight = true;
     if (kTimers && !STATS) {   // development build: print where the waves' cycles went
         unsigned long long h[128];
         HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
@@ -551,19 +594,23 @@ int rt_create(int device_id, rt_ctx **out) {
 void rt_destroy(rt_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();   // renders may still be in flight on the caller's streams and the pipelines'
     free_all(ctx->scene_allocs);
     free_all(ctx->sampler_allocs);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
-    if (ctx->wf_pool) (void)hipFree(ctx->wf_pool);
-    if (ctx->wf_samples) (void)hipFree(ctx->wf_samples);
-    if (ctx->wf_ctr) (void)hipFree(ctx->wf_ctr);
-    if (ctx->wf_ovf) (void)hipFree(ctx->wf_ovf);
-    if (ctx->wf_host_status) (void)hipHostFree(ctx->wf_host_status);
-    for (auto &evs : ctx->wf_event) for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : ctx->wf_join) if (ev) (void)hipEventDestroy(ev);
-    if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
-    for (hipStream_t st : ctx->wf_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (WfSpace &S : ctx->wf) {
+        if (S.in_flight && S.done) (void)hipEventSynchronize(S.done);
+        for (hipStream_t st : S.stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        if (S.pool) (void)hipFree(S.pool);
+        if (S.samples) (void)hipFree(S.samples);
+        if (S.ctr) (void)hipFree(S.ctr);
+        if (S.ovf) (void)hipFree(S.ovf);
+        if (S.host_status) (void)hipHostFree(S.host_status);
+        for (auto &evs : S.event) for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : S.join) if (ev) (void)hipEventDestroy(ev);
+        if (S.fork) (void)hipEventDestroy(S.fork);
+        if (S.done) (void)hipEventDestroy(S.done);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -765,6 +812,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     int st = set_device(ctx);
     if (st) return st;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((st = settle_all(ctx)) != RT_OK) return st;     // renders in flight read the tables released below
     free_all(ctx->scene_allocs);
     ctx->have_scene = false;
     DScene &d = ctx->sc;
@@ -966,6 +1014,7 @@ int rt_sampler_upload(rt_ctx *ctx, const rt_sampler_desc *s) {
     int st = set_device(ctx);
     if (st) return st;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((st = settle_all(ctx)) != RT_OK) return st;
     free_all(ctx->sampler_allocs);
     ctx->have_sampler = false;
     auto &own = ctx->sampler_allocs;
@@ -1231,6 +1280,8 @@ int rt_synchronize(rt_ctx *ctx, void *stream) {
     if (st) return st;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : nullptr));
+    for (WfSpace &S : ctx->wf)      // frames that have ended by now: look at how they ended
+        if (S.in_flight && hipEventQuery(S.done) == hipSuccess && (st = settle(ctx, S)) != RT_OK) return st;
     return RT_OK;
 }
 
