@@ -169,13 +169,13 @@ class Bench:
         # is checked against the counting run's image afterwards.  --frames 1: one stream, one buffer, one frame at a time.
         # N > 1: the exchange of frame k runs on a stream of its own, behind that frame's render (the collective is a copy over
         # xGMI, the render is compute: they overlap); every reduce is inside the timed region (barrier + synchronize below)
-        n_fl = 2 if (self.comm is not None or args.frames > 1) else 1
+        n_fl = max(2, args.frames) if (self.comm is not None or args.frames > 1) else 1
         accs = [acc] + [torch.zeros_like(acc) for _ in range(n_fl - 1)]
         streams = [self.stream] + [torch.cuda.Stream(device=dev) for _ in range(n_fl - 1)] if args.frames > 1 else [self.stream] * n_fl
         comm_stream = torch.cuda.Stream(device=dev) if self.comm is not None else None
         rendered = [torch.cuda.Event() for _ in accs]
         reduced = [torch.cuda.Event() for _ in accs]
-        for k in range(min(warmup, 2) * n_fl if n_fl > 1 else 0):     # untimed: the second workspace and its streams come into being
+        for k in range(min(warmup, 2) * n_fl if args.frames > 1 else 0):     # untimed: the second workspace and its streams come into being
             with torch.cuda.stream(streams[k % n_fl]):
                 accs[k % n_fl].zero_()
                 gpu.render_device(params, camera, accs[k % n_fl].data_ptr(), streams[k % n_fl].cuda_stream, spp_begin=spp_begin, spp_count=spp_count)
@@ -315,7 +315,7 @@ def main():
     ap.add_argument("--workload", default="C1")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
-    ap.add_argument("--frames", type=int, default=2, choices=[1, 2], help="frames in flight: 2 = consecutive frames on two streams and two buffers (default), 1 = one at a time")
+    ap.add_argument("--frames", type=int, default=2, choices=[1, 2, 3], help="frames in flight: 2 = consecutive frames on two streams and two buffers (default), 1 = one at a time (3: A/B only, the library keeps two workspaces)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="skip the C2 / C3 / C4 sub-workloads of the default run")
     ap.add_argument("--sub", default=None, help="comma-separated sub-workloads instead of C2,C3,C4")
@@ -339,7 +339,7 @@ def main():
     if args.frames > 1:
         # two frames in flight = two caller streams + two pipeline streams per frame: with HIP's default of 4 hardware queues
         # per process they share queues and run one after the other (profiles/r3/ab_frames_in_flight.txt); read at HIP start-up
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(4 * args.frames))
     import torch
     import rtiow_loader
     rt = rtiow_loader.load()

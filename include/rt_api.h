@@ -250,10 +250,17 @@ int rt_sampler_upload(rt_ctx *ctx, const rt_sampler_desc *sampler);
  * Replaces the worker loop + Camera::raytrace_pixel, main.rs:1337-1361, camera.rs:186-309.
  * With out_location = RT_MEM_DEVICE the work is ordered on params->stream (it starts after what the
  * caller queued there, and what the caller queues next sees the image); the call itself returns once
- * the last kernels are queued, which is when the pool of in-flight paths has drained — the host
- * feeds the pipeline, so for the host it lasts about as long as the render.  `cancel` is polled
- * between groups of eight iterations.  The context keeps a workspace in device memory between calls
- * (path pool 1.2 GB, sample buffer up to RT_WF_SAMPLES_MB = 8192 MB; grown on demand). */
+ * the frame's last kernels are queued — the host feeds the pipeline, so for the host it lasts nearly as
+ * long as the render, less the frame's last launches (the few paths still alive then: a fifth of a
+ * 10-spp frame of Book-1).  `cancel` is polled between groups of eight iterations.
+ * FRAMES IN FLIGHT: the context keeps two workspaces in device memory (each: path pool 1.2 GB, sample
+ * buffer up to RT_WF_SAMPLES_MB = 8192 MB; grown on demand, kept until rt_destroy) and uses them in turn,
+ * so a call ordered on ANOTHER stream than the one before starts while that one's last launches still
+ * run (rt_stream_create; different output buffers, or the caller orders the calls: the sums are added
+ * into out_rgba_sum by the frame's last kernel).  Calls on one stream run one after the other as before.
+ * A third call first waits for the first to end; rt_scene_upload, rt_sampler_upload and rt_destroy wait
+ * for every frame in flight.  (HIP gives a process 4 hardware queues by default and then lets the streams
+ * of two frames share them, which serialises the frames: set GPU_MAX_HW_QUEUES=8 in the environment.) */
 int rt_render(rt_ctx *ctx, const rt_render_params *params, float *out_rgba_sum, rt_stats *stats);
 
 /* The counters of the last rt_render with collect_stats = 1, split by the kernel that did the work: 0 generate (camera rays and
@@ -314,6 +321,13 @@ int rt_device_alloc(rt_ctx *ctx, size_t bytes, void **out_device_ptr);
 int rt_device_free(rt_ctx *ctx, void *device_ptr);
 int rt_device_zero(rt_ctx *ctx, void *device_ptr, size_t bytes, void *stream);
 int rt_device_read(rt_ctx *ctx, void *dst_host, const void *src_device, size_t bytes, void *stream);
+/* ... and streams for it (hipStream_t as void*, non-blocking): what rt_render, rt_resolve, rt_device_* and the reduces take as
+ * `stream`.  rt_stream_wait orders what is queued on `stream` from now on behind what is queued on `after` so far (NULL = the
+ * default stream).  rt_stream_destroy waits for the stream's work.  NO COUNTERPART IN THE REFERENCE (its frames are one
+ * thread-pool job each): two streams are what lets two frames be in flight (rt_render). */
+int rt_stream_create(rt_ctx *ctx, void **out_stream);
+int rt_stream_destroy(rt_ctx *ctx, void *stream);
+int rt_stream_wait(rt_ctx *ctx, void *stream, void *after);
 typedef struct rt_comm rt_comm;
 int rt_comm_unique_id(char id[RT_COMM_ID_BYTES]);
 int rt_comm_create(rt_ctx *ctx, const char id[RT_COMM_ID_BYTES], int rank, int world, rt_comm **out);

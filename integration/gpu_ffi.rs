@@ -249,6 +249,9 @@ extern "C" {
     pub fn rt_device_free(ctx: *mut rt_ctx, device_ptr: *mut c_void) -> c_int;
     pub fn rt_device_zero(ctx: *mut rt_ctx, device_ptr: *mut c_void, bytes: usize, stream: *mut c_void) -> c_int;
     pub fn rt_device_read(ctx: *mut rt_ctx, dst_host: *mut c_void, src_device: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn rt_stream_create(ctx: *mut rt_ctx, out_stream: *mut *mut c_void) -> c_int;
+    pub fn rt_stream_destroy(ctx: *mut rt_ctx, stream: *mut c_void) -> c_int;
+    pub fn rt_stream_wait(ctx: *mut rt_ctx, stream: *mut c_void, after: *mut c_void) -> c_int;
     pub fn rt_comm_unique_id(id: *mut c_char) -> c_int;
     pub fn rt_comm_create(ctx: *mut rt_ctx, id: *const c_char, rank: c_int, world: c_int, out: *mut *mut rt_comm) -> c_int;
     pub fn rt_comm_reduce_to_root(comm: *mut rt_comm, rgba_sum_device: *mut f32, n_floats: i64, root: c_int, stream: *mut c_void) -> c_int;

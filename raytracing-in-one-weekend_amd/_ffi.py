@@ -193,6 +193,7 @@ HIP_SYMBOLS = [
     "rt_trace_first_hit_noalloc", "rt_last_kernel_stats",
     "rt_comm_unique_id", "rt_comm_create", "rt_comm_reduce_to_root", "rt_comm_destroy",
     "rt_device_alloc", "rt_device_free", "rt_device_zero", "rt_device_read",
+    "rt_stream_create", "rt_stream_destroy", "rt_stream_wait",
     "rt_group_create", "rt_group_size", "rt_group_ctx", "rt_group_reduce_to_root", "rt_group_destroy",
 ]
 RT_COMM_ID_BYTES = 128
@@ -316,6 +317,9 @@ def hip_lib():
     L.rt_device_free.argtypes = [vp, vp]
     L.rt_device_zero.argtypes = [vp, vp, C.c_size_t, vp]
     L.rt_device_read.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.rt_stream_create.argtypes = [vp, C.POINTER(vp)]
+    L.rt_stream_destroy.argtypes = [vp, vp]
+    L.rt_stream_wait.argtypes = [vp, vp, vp]
     L.rt_comm_unique_id.argtypes = [C.c_char_p]
     L.rt_comm_create.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(vp)]
     L.rt_comm_reduce_to_root.argtypes = [vp, vp, C.c_int64, i32, vp]

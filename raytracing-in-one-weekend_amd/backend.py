@@ -171,6 +171,19 @@ class HipBackend:
         self._check(self._L.rt_device_read(self._h, out.ctypes.data, ptr, out.nbytes, stream_ptr))
         return out
 
+    def stream_create(self):
+        """A HIP stream of the context's device (its address as an int), for render_device and friends."""
+        s = C.c_void_p()
+        self._check(self._L.rt_stream_create(self._h, C.byref(s)))
+        return s.value
+
+    def stream_destroy(self, stream_ptr):
+        self._check(self._L.rt_stream_destroy(self._h, stream_ptr))
+
+    def stream_wait(self, stream_ptr, after_ptr):
+        """What is queued on stream_ptr from now on runs after what is queued on after_ptr so far."""
+        self._check(self._L.rt_stream_wait(self._h, stream_ptr, after_ptr))
+
     def synchronize(self, stream_ptr=None):
         self._check(self._L.rt_synchronize(self._h, stream_ptr))
 

@@ -139,6 +139,41 @@ int rt_device_read(rt_ctx *ctx, void *dst_host, const void *src_device, size_t b
     return RT_OK;
 }
 
+int rt_stream_create(rt_ctx *ctx, void **out) {
+    if (!ctx) return RT_E_INVALID;
+    if (!out) return ctx_fail(ctx, RT_E_INVALID, "rt_stream_create: out is NULL");
+    *out = nullptr;
+    if (hipSetDevice(ctx_device(ctx)) != hipSuccess) return ctx_fail(ctx, RT_E_HIP, "rt_stream_create: hipSetDevice failed");
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) return ctx_fail(ctx, RT_E_HIP, "rt_stream_create: %s", hipGetErrorString(e));
+    *out = s;
+    return RT_OK;
+}
+
+int rt_stream_destroy(rt_ctx *ctx, void *stream) {
+    if (!ctx) return RT_E_INVALID;
+    if (!stream) return RT_OK;
+    if (hipSetDevice(ctx_device(ctx)) != hipSuccess) return ctx_fail(ctx, RT_E_HIP, "rt_stream_destroy: hipSetDevice failed");
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) return ctx_fail(ctx, RT_E_HIP, "rt_stream_destroy: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_stream_wait(rt_ctx *ctx, void *stream, void *after) {
+    if (!ctx) return RT_E_INVALID;
+    if (stream == after) return RT_OK;      // a stream is in order with itself
+    if (hipSetDevice(ctx_device(ctx)) != hipSuccess) return ctx_fail(ctx, RT_E_HIP, "rt_stream_wait: hipSetDevice failed");
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ev, (hipStream_t)after);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, ev, 0);
+    if (ev) (void)hipEventDestroy(ev);      // (released by the runtime once the wait has been satisfied)
+    if (e != hipSuccess) return ctx_fail(ctx, RT_E_HIP, "rt_stream_wait: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
 int rt_comm_unique_id(char id[RT_COMM_ID_BYTES]) {
     static_assert(RT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "rt_api.h and rccl.h disagree on the id size");
     if (!id) return ctx_fail(nullptr, RT_E_INVALID, "rt_comm_unique_id: id is NULL");

@@ -26,7 +26,7 @@ def test_hip_library_exports_rt_api_h(rt):
     assert os.path.exists(path), "HIP extension not built: run __graft_entry__.build()"
     L = ctypes.CDLL(path)   # links libamdhip64; needs no GPU
     names = declared("rt_api.h", "rt_")
-    assert len(names) == 29      # the 14 of round 1 + rt_trace_first_hit_noalloc + rt_device_* (4) + rt_comm_* (4) + rt_group_* (5) + rt_last_kernel_stats
+    assert len(names) == 32      # the 14 of round 1 + rt_trace_first_hit_noalloc + rt_device_* (4) + rt_stream_* (3) + rt_comm_* (4) + rt_group_* (5) + rt_last_kernel_stats
     for n in names:
         assert hasattr(L, n), n
     assert sorted(rt._ffi.HIP_SYMBOLS) == names

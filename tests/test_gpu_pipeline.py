@@ -164,3 +164,39 @@ def test_depth_zero_and_empty_ranges(rt, gpu, book2):
     p0 = params.replace(max_ray_depth=0)                               # ray_color returns black at depth 0 (camera.rs:258-262)
     got, _ = gpu.render(p0, camera)
     assert np.all(got[..., :3] == 0.0) and np.all(got[..., 3] == sampler.spp)
+
+
+@pytest.mark.parametrize("env", [{}, {"RT_WF_HAND_OFF": 0}, {"RT_WF_FRAMES": 1}, {"RT_WF_PIPES": 1}, {"RT_WF_SAMPLES_MB": 4}])   # (4 MB: the large frames go one sample per batch)
+def test_frames_in_flight_on_two_streams_equal_the_frames_one_by_one(gpu, book2, env):
+    # rt_render returns once a frame's last kernels are queued and keeps a workspace per frame in flight (rt_device.hip, WfSpace):
+    # frames ordered on two streams, at two sizes, must be the frames rendered one at a time; uploads behind them wait for them
+    scene, params, camera, sampler, ref = book2
+    W, H = params.image_width, params.image_height
+    frames = [(0x5EED, W, H), (7, 4 * W, 4 * H), (0x5EED, W, H), (9, 4 * W, 4 * H), (11, W, H), (0x5EED, W, H)]
+    want = [gpu.render(params, camera, seed=s, width=w, height=h)[0] for s, w, h in frames]
+    assert same_bits(want[0], ref) and same_bits(want[5], ref)
+    streams = [gpu.stream_create(), gpu.stream_create()]
+    bufs = [gpu.device_alloc(w * h * 16) for _, w, h in frames]
+    try:
+        with knobs(**env):
+            for k, (s, w, h) in enumerate(frames):
+                st = streams[k % 2]
+                gpu.device_zero(bufs[k], w * h * 16, st)
+                gpu.render_device(params, camera, bufs[k], st, seed=s, width=w, height=h)
+            gpu.upload_sampler(sampler)          # releases the tables the frames in flight read: has to wait for them
+            for k, (s, w, h) in enumerate(frames):
+                got = gpu.device_read(bufs[k], (h, w, 4), stream_ptr=streams[k % 2])
+                assert same_bits(got, want[k]), "frame %d (%r)" % (k, env)
+            # the same buffer on both streams in turn, each call behind the other's (the caller orders them): sums of two frames
+            gpu.device_zero(bufs[0], W * H * 16, streams[0])
+            for k in range(4):
+                if k:
+                    gpu.stream_wait(streams[k % 2], streams[(k - 1) % 2])
+                gpu.render_device(params, camera, bufs[0], streams[k % 2], spp_begin=4 * k, spp_count=4)
+            got = gpu.device_read(bufs[0], (H, W, 4), stream_ptr=streams[1])
+            assert same_bits(got, ref)
+    finally:
+        for st in streams:
+            gpu.stream_destroy(st)
+        for b in bufs:
+            gpu.device_free(b)
