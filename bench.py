@@ -339,7 +339,9 @@ def main():
     if args.frames > 1:
         # two frames in flight = two caller streams + two pipeline streams per frame: with HIP's default of 4 hardware queues
         # per process they share queues and run one after the other (profiles/r3/ab_frames_in_flight.txt); read at HIP start-up
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(4 * args.frames))
+        # (the GPU boxes export the default, 4, so the variable is raised rather than defaulted)
+        if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 4 * args.frames:
+            os.environ["GPU_MAX_HW_QUEUES"] = str(4 * args.frames)
     import torch
     import rtiow_loader
     rt = rtiow_loader.load()

@@ -141,6 +141,14 @@ typedef struct rt_scene_desc {
        by the build; the always-list must be the tail of the slot array.  bvh_nodes / bvh_root_ref /
        bvh_stack_depth are ignored.  bvh_leaf_max: 1 or 2 slots per leaf, 0 = the library's choice. */
     const float   *slot_boxes;      uint32_t build_bvh_on_device;   /* rt_bvh_build */   uint32_t bvh_leaf_max;
+    /* Rays that start further than this (on some axis) from the middle of the scene's spheres see what HittableList::hit sees
+       (hittable_list.rs:39-50): in f32, sphere.rs:46-66 accepts small spheres thousands of radii away by cancellation and the
+       reference's flat `world` takes those hits, which a walk that culls by the spheres' boxes would never test.  For such a
+       ray the kernels grow every box by the distance at which that can happen (rt_kernels.h, ray_fat), so no leaf whose exact
+       test could accept the ray is culled.  The host flatten sets 2^10 x the smallest sphere radius when `world` holds no
+       BvhNode and +inf when it does (the reference then culls by boxes itself, bvh.rs:73-91); 0 = the library derives it
+       from the slots as for a flat list. */
+    float          far_limit;
 } rt_scene_desc;
 
 /* rt_scene_desc.build_bvh_on_device: who builds the tree.  RT_BVH_DEVICE = parallel locally-ordered clustering over Morton-sorted

@@ -40,7 +40,7 @@ pub enum rth_config {}
 pub enum rth_geometry {}
 pub enum rtg_graph {} // only ever passed through (rth_scene_graph -> rth_flatten)
 
-/// rt_scene_desc (rt_api.h): sizeof 240
+/// rt_scene_desc (rt_api.h): sizeof 248
 #[repr(C)]
 pub struct rt_scene_desc {
     pub struct_size: u32,            // 0
@@ -77,6 +77,7 @@ pub struct rt_scene_desc {
     pub slot_boxes: *const f32,      // 224
     pub build_bvh_on_device: u32,    // 232
     pub bvh_leaf_max: u32,           // 236
+    pub far_limit: f32,              // 240
 }
 
 /// rt_scene_info: sizeof 28

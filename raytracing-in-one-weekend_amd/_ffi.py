@@ -48,6 +48,7 @@ class rt_scene_desc(C.Structure):
         ("n_prims", C.c_uint32),
         ("matrices", c_float_p), ("n_matrices", C.c_uint32),
         ("slot_boxes", c_float_p), ("build_bvh_on_device", C.c_uint32), ("bvh_leaf_max", C.c_uint32),
+        ("far_limit", C.c_float),
     ]
 
 

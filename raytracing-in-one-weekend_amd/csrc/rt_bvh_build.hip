@@ -378,7 +378,7 @@ int build_bvh(hipStream_t stream, const float *d_boxes, uint32_t n, uint32_t lea
             auto *valid = (uint32_t *)(scratch + o_va), *vpos = (uint32_t *)(scratch + o_vp), *merger = (uint32_t *)(scratch + o_me), *mpos = (uint32_t *)(scratch + o_mp);
             hipLaunchKernelGGL(ploc_init_kernel, dim3(gn), dim3(256), 0, stream, d_boxes, sorted_prim, (int)n, cb[0], ci[0]);
             int c = (int)n, node_base = 0, cur = 0, pair_up = 0, radius = RTB_PLOC_RADIUS;
-            if (const char *e = getenv("RT_BVH_PLOC_RADIUS")) { const int v = atoi(e); if (v >= 1 && v <= 256) radius = v; }
+            if (const char *e = getenv("RT_KNOBS") ? getenv("RT_BVH_PLOC_RADIUS") : nullptr) { const int v = atoi(e); if (v >= 1 && v <= 256) radius = v; }
             for (int round = 0; c > 1; ++round) {
                 if (round > 4096) { *err = "device BVH build: clustering does not converge"; return done(RT_E_HIP); }
                 const unsigned gc = ((unsigned)c + 255u) / 256u;

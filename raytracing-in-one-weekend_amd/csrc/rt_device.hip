@@ -122,8 +122,13 @@ int set_device(rt_ctx *ctx) {
     return RT_OK;
 }
 
+// Tuning knobs (RT_WF_*, RT_NOISE_COOP, RT_KERNEL_SET: INTEGRATION.md) exist for the tests, which prove that none of them changes
+// a bit of the image, and for A/B measurements.  They are read from the environment only when RT_KNOBS is set there as well, so
+// a product run is what this file's defaults say, whatever else its environment holds.
+const char *knob(const char *name) { return getenv("RT_KNOBS") ? getenv(name) : nullptr; }
+
 size_t env_size(const char *name, size_t dflt, size_t lo, size_t hi) {
-    if (const char *e = getenv(name)) {
+    if (const char *e = knob(name)) {
         long long v = atoll(e);
         if (v >= (long long)lo && v <= (long long)hi) return (size_t)v;
     }
@@ -313,7 +318,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     int per_cu = 0;
     // two instances of the traversal kernel: scenes with a general Transform inside the BVH need the code for it in the leaf step
     int features = ctx->features;
-    if (const char *e = getenv("RT_KERNEL_SET")) { if (!strcmp(e, "full")) features |= KS_FULL; }   // A/B: run a scene on the full set
+    if (const char *e = knob("RT_KERNEL_SET")) { if (!strcmp(e, "full")) features |= KS_FULL; }   // A/B: run a scene on the full set
     const WfKernels<STATS> K = wf_kernels<STATS>(features, ctx->bvh_has_general_xform);
     auto *const trav_kernel = n_top ? K.traverse_top : K.traverse;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel, 256, lds));
@@ -411,7 +416,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
             // always-list (Cornell, Blocks) or nearly so (GeometricPrimitives: 7 quadrics and a tree of a dozen nodes) keeps raster
             // order, which is kinder to its texture and sample-buffer accesses (+6 % there)
             const bool balanced = has_bvh && ctx->n_bvh_nodes >= 64u;
-            w.tile_stride = (balanced || getenv("RT_WF_TILE_STRIDE")) ? tile_stride_for(w.tiles_pipe) : 1u;
+            w.tile_stride = (balanced || knob("RT_WF_TILE_STRIDE")) ? tile_stride_for(w.tiles_pipe) : 1u;
             w.tail_max = tail_max;
             // the material deal of the shade kernel: not for the small feature set without a tree (Cornell-type scenes: nearly all
             // hits are one kind there); RT_WF_SORT_BLOCKS=0 / 1 forces it
@@ -676,11 +681,16 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     }
     bool tris = false, general_in_bvh = false;
     int need = s->n_media ? EXT_MEDIA : EXT_NONE;     // EXT_* features the scene needs (kernel set, rt_kernels.h)
+    float r_min = INFINITY;      // smallest sphere radius (ray_is_far, rt_kernels.h)
     for (uint32_t i = 0; i < s->n_slots; ++i) {
         int32_t w4, mat;
         memcpy(&w4, &s->slots[i * RT_SLOT_FLOATS + 4], 4);
         memcpy(&mat, &s->slots[i * RT_SLOT_FLOATS + 5], 4);
         int type = w4 & 15, xf = (w4 >> 8) - 1;
+        if (type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE) {
+            const float rad = fabsf(s->slots[i * RT_SLOT_FLOATS + 3]);
+            if (rad > 0.0f && rad < r_min) r_min = rad;
+        }
         if (type > RT_PRIM_HYPERBOLOID) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "slot %u: primitive type %d", i, type);
         if (xf >= (int)s->n_xforms) return fail(ctx, RT_E_INVALID, "slot %u: xform out of range", i);
         bool general = false, chain = false;
@@ -979,6 +989,34 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     d.n_slots = s->n_slots;
     d.always_begin = s->always_begin; d.always_count = s->always_count;
     d.n_media = s->n_media; d.n_lights = s->n_lights; d.n_moving = s->n_moving_slots; d.n_rects = s->n_rect_slots;
+    d.far_limit = s->far_limit > 0.0f ? s->far_limit : r_min * 1024.0f;     // (rt_api.h; no spheres: infinity)
+    {   // ... measured from the middle of the spheres of ordinary size (a ground sphere of 5 000 smallest radii is not one)
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < s->n_slots; ++i) {
+            int32_t w4;
+            memcpy(&w4, &s->slots[i * RT_SLOT_FLOATS + 4], 4);
+            const int type = w4 & 15;
+            const float *q = &s->slots[i * RT_SLOT_FLOATS];
+            if ((type != RT_PRIM_SPHERE && type != RT_PRIM_MOVING_SPHERE) || !(fabsf(q[3]) <= 64.0f * r_min)) continue;
+            for (int k = 0; k < 3; ++k) { if (q[k] < lo[k]) lo[k] = q[k]; if (q[k] > hi[k]) hi[k] = q[k]; }
+        }
+        for (int k = 0; k < 3; ++k) d.far_centre[k] = (lo[k] <= hi[k] && std::isfinite(lo[k]) && std::isfinite(hi[k])) ? 0.5f * (lo[k] + hi[k]) : 0.0f;
+        double reach = 0.0;      // ... and how far the centre of one of them lies from there at most (a MovingSphere: either end of its way)
+        for (uint32_t i = 0; i < s->n_slots; ++i) {
+            int32_t w4;
+            memcpy(&w4, &s->slots[i * RT_SLOT_FLOATS + 4], 4);
+            const int type = w4 & 15;
+            if ((type != RT_PRIM_SPHERE && type != RT_PRIM_MOVING_SPHERE) || !(fabsf(s->slots[i * RT_SLOT_FLOATS + 3]) <= 64.0f * r_min)) continue;
+            for (int e = 0; e < (type == RT_PRIM_MOVING_SPHERE ? 2 : 1); ++e) {
+                const float *q = &s->slots[i * RT_SLOT_FLOATS + (e ? 8 : 0)];
+                double d2 = 0.0;
+                for (int k = 0; k < 3; ++k) d2 += ((double)q[k] - d.far_centre[k]) * ((double)q[k] - d.far_centre[k]);
+                if (std::isfinite(d2) && d2 > reach) reach = d2;
+            }
+        }
+        d.far_reach = (float)(std::sqrt(reach) * 1.0001);
+        d.far_rmin = std::isfinite(r_min) ? r_min : 0.0f;
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_scene = true;
     return RT_OK;

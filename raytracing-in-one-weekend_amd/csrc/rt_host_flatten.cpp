@@ -75,6 +75,8 @@ struct rth_flat {
     int32_t root_ref = RT_BVH_EMPTY;
     uint32_t stack_depth = 1, always_begin = 0, always_count = 0, n_prims = 0;
     bool has_tris = false;
+    bool saw_bvh = false;            // `world` holds a BvhNode somewhere (rt_scene_desc::far_limit)
+    float r_min = INFINITY;          // smallest sphere radius
 };
 
 namespace {
@@ -204,12 +206,14 @@ struct Flattener {
         case RTG_SPHERE: {
             float q0[4] = {n.f[0], n.f[1], n.f[2], n.f[3]};
             float r = std::fabs(n.f[3]);
+            if (r > 0.0f && r < out->r_min) out->r_min = r;
             Box b{{n.f[0] - r, n.f[1] - r, n.f[2] - r}, {n.f[0] + r, n.f[1] + r, n.f[2] + r}};
             emit(RT_PRIM_SPHERE, w, n.material, q0, 0.0f, nullptr, b, nullptr);
             return true;
         }
         case RTG_MOVING_SPHERE: {
             float r = std::fabs(n.f[8]);
+            if (r > 0.0f && r < out->r_min) out->r_min = r;
             float q0[4] = {n.f[0], n.f[1], n.f[2], n.f[8]};
             float q2[4] = {n.f[3], n.f[4], n.f[5], n.f[7]};
             Box b;
@@ -308,6 +312,7 @@ struct Flattener {
             return walk(ch[0], w, depth + 1);
         }
         case RTG_BVH: case RTG_LIST:
+            if (n.type == RTG_BVH) out->saw_bvh = true;
             for (int i = 0; i < n.child_count; ++i)
                 if (!walk(ch[i], w, depth + 1)) return false;
             return true;
@@ -493,7 +498,7 @@ struct BvhBuilder {
 
     explicit BvhBuilder(const std::vector<Box> &b) : boxes(b) {
         kLeafMax = b.size() >= 100000 ? 2 : 1;
-        if (const char *e = getenv("RTH_BVH_LEAF_MAX")) { int v = atoi(e); if (v >= 1 && v <= 4) kLeafMax = v; }
+        if (const char *e = getenv("RT_KNOBS") ? getenv("RTH_BVH_LEAF_MAX") : nullptr) { int v = atoi(e); if (v >= 1 && v <= 4) kLeafMax = v; }
     }
 
     Box range_box(uint32_t b, uint32_t e) const {
@@ -661,7 +666,7 @@ int rth_flatten_opts(const rtg_graph *g, uint32_t flags, rth_flat **out_flat) {
     for (size_t i = 0; i < n_all; ++i) (fl.always[i] ? in_always : in_bvh).push_back((uint32_t)i);
     const size_t n = in_bvh.size();
     size_t flat_max = 24;   // measured on MI355X: Cornell box (13 leaves) and Blocks (20) are faster as a flat scan (Blocks: 10.5 vs 9.1 Grays/s)
-    if (const char *e = getenv("RTH_FLAT_MAX")) { int v = atoi(e); if (v >= 0 && v <= 4096) flat_max = (size_t)v; }
+    if (const char *e = getenv("RT_KNOBS") ? getenv("RTH_FLAT_MAX") : nullptr) { int v = atoi(e); if (v >= 0 && v <= 4096) flat_max = (size_t)v; }
     if (n <= flat_max) {  // tiny scenes (Cornell box: 13 leaves): a flat scan beats any tree
         flat->slots = fl.prims;
         flat->attrs = fl.pattrs;
@@ -823,6 +828,7 @@ void rth_flat_desc(const rth_flat *f, rt_scene_desc *d) {
     d->moving_slots = f->moving.data();        d->n_moving_slots = (uint32_t)f->moving.size();
     d->rect_slots = f->rects.data();           d->n_rect_slots = (uint32_t)f->rects.size();
     d->n_prims = f->n_prims;
+    d->far_limit = f->saw_bvh ? INFINITY : f->r_min * 1024.0f;
 }
 
 }  // extern "C"

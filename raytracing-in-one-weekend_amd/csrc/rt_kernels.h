@@ -13,8 +13,8 @@
 // (64-byte nodes holding the four child boxes quantised to 8 bits on the node's own grid, 64-byte primitive slots),
 // walked with a per-lane stack of node refs in LDS (overflow in HBM).  It reproduces HittableList::hit semantics
 // (hittable_list.rs:39-50): closest t, and on an exact tie the object later in the list — the larger primitive id —
-// wins.  Tests that can be rejected without the reference's exact arithmetic are rejected by conservative
-// pre-tests (boxes; the always-list's reciprocal-estimate filter); whatever is accepted went through the exact test.
+// wins.  The only tests decided without the reference's exact arithmetic are the walk's box tests, which are conservative
+// (a box is widened by its quantisation and a rounding margin): whatever is accepted as a hit went through the exact test.
 #ifndef RT_KERNELS_H
 #define RT_KERNELS_H
 
@@ -105,6 +105,9 @@ struct DScene {
     const uint32_t *top_order;
     const uint32_t *top_child;
     uint32_t n_top;
+    // rays that start further than far_limit (on some axis) from far_centre walk the tree with every box grown (ray_fat):
+    // far_reach = how far the centre of a sphere of ordinary size lies from far_centre at most, far_rmin = the smallest sphere radius
+    float far_limit, far_centre[3], far_reach, far_rmin;
 };
 
 #define RT_N_REGIONS 24
@@ -609,6 +612,35 @@ RT_DEV void consider(Hit &best, float t, int32_t id, int32_t slot) {
     if (t < best.t || (t == best.t && id > best.id)) { best.t = t; best.id = id; best.slot = slot; }
 }
 
+// Rays from far away.  sphere.rs:46-66 in f32 loses the discriminant to cancellation when the ray starts thousands of radii from
+// the sphere: half_b^2 - a*c is the difference of two numbers of size |oc|^2 |d|^2, and the roundings on the way to it (oc, two
+// three-term dot products and a norm without contraction, the squares and the product: u = 2^-24 each) add up to less than
+// 15 u |oc|^2 |d|^2 + 2 u r^2 |d|^2 < eps |oc|^2 |d|^2 with eps = 2^-20.  The true value is |d|^2 (r^2 - dist^2), dist = the
+// distance of the centre from the ray's line, so the test can accept a sphere the ray passes at up to sqrt(r^2 + eps |oc|^2)
+// from its centre, and the root it then reports lies within sqrt(eps) |oc| of the point of closest approach along the ray —
+// nowhere near the sphere.  (The length of d does not matter: it scales everything alike.)  The reference's flat `world` takes
+// such a hit (hittable_list.rs:39-50); a walk that culls by the sphere's box never gets to test it.  So a ray that starts
+// further than far_limit (2^10 x the smallest sphere radius, rt_api.h) from the middle of the scene's spheres walks the tree
+// with every box grown by
+//      sqrt(r_min^2 + eps D^2) - r_min  +  sqrt(eps) D,      D = |o - middle| + far_reach >= |oc| for every sphere of ordinary size,
+// the most the ray can miss a sphere by and the most the reported root can lie beyond that: whatever its exact test can
+// accept, with whatever t, it reaches.  (Spheres of more than 64 smallest radii — the r = 1000 ground of RandomWorld — are left
+// to the padding of their boxes, 1e-4 of their coordinates: the band in which they can be mis-accepted is eps |oc|^2 / 2r wide,
+// 0.009 for that ground from 3 000 units away.)  Path segments inside the ground sphere of RandomWorld are such rays (one path
+// in 10 000 gets in there and bounces to the depth limit); an Orthographic view plane that dips into it makes them by the
+// thousand.  0 = an ordinary ray.  -DRT_FAR_WALK=0 compiles the growth out (A/B: profiles/r3/ab_far_rays.txt).
+#ifndef RT_FAR_WALK
+#define RT_FAR_WALK 1
+#endif
+RT_DEV float ray_fat(const DScene &sc, const Ray &r) {
+    if (!RT_FAR_WALK) return 0.0f;
+    const float dx = r.o.x - sc.far_centre[0], dy = r.o.y - sc.far_centre[1], dz = r.o.z - sc.far_centre[2];
+    if (!(fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) > sc.far_limit)) return 0.0f;
+    const float D = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) * 1.000001f + sc.far_reach;
+    const float s = 9.765625e-4f * D;        // sqrt(eps) D
+    return (__builtin_sqrtf(__builtin_fmaf(s, s, sc.far_rmin * sc.far_rmin)) - sc.far_rmin) + s;
+}
+
 // 1 / d for the box tests only.  A component below 1e-30 in magnitude is replaced by 1e-30, so the reciprocal stays finite
 // and lo*inv - o*inv cannot turn into inf - inf; the reciprocal is the hardware estimate (v_rcp_f32, 1 ulp) instead of three
 // IEEE divisions of ~10 instructions each: a relative error of 1.2e-7 in a box's ray parameters is three orders of magnitude
@@ -684,9 +716,9 @@ struct TopLds {
     uint32_t count;
 };
 
-template <bool STATS, bool LT = false>
+template <bool STATS, bool LT = false, bool FAT = false>
 RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t_min, float best_t, const Stack &stack, uint32_t &sp, Counters &cnt,
-                           const TopLds &top = TopLds{(LdsF4Ptr)0, 0u}) {
+                           const TopLds &top = TopLds{(LdsF4Ptr)0, 0u}, float fat = 0.0f) {
     float4 n0, n1, n2, rf;
     if (LT && (ref & RT_TOP_FLAG)) {
         const LdsF4Ptr n = top.img + (uint32_t)(ref & ~RT_TOP_FLAG);
@@ -698,6 +730,9 @@ RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t
     // plane = origin + scale * q, so its ray parameter (plane - o) * inv is q * (scale * inv) + (origin * inv - o * inv)
     const float sx = n0.w * inv.x, sy = n1.x * inv.y, sz = n1.y * inv.z;
     const float ox = __builtin_fmaf(n0.x, inv.x, -oi.x), oy = __builtin_fmaf(n0.y, inv.y, -oi.y), oz = __builtin_fmaf(n0.z, inv.z, -oi.z);
+    // FAT (ray_fat): every box grown by `fat` on all sides — its near planes' parameters come earlier by fat * |inv|, its far planes' later
+    const float ex = FAT ? fat * fabsf(inv.x) : 0.0f, ey = FAT ? fat * fabsf(inv.y) : 0.0f, ez = FAT ? fat * fabsf(inv.z) : 0.0f;
+    const float oxn = FAT ? ox - ex : ox, oxf = FAT ? ox + ex : ox, oyn = FAT ? oy - ey : oy, oyf = FAT ? oy + ey : oy, ozn = FAT ? oz - ez : oz, ozf = FAT ? oz + ez : oz;
     const uint32_t qlx = __float_as_uint(n1.z), qhx = __float_as_uint(n1.w), qly = __float_as_uint(n2.x), qhy = __float_as_uint(n2.y),
                    qlz = __float_as_uint(n2.z), qhz = __float_as_uint(n2.w);
     const bool bx = inv.x < 0.0f, by = inv.y < 0.0f, bz = inv.z < 0.0f;
@@ -709,9 +744,9 @@ RT_DEV int32_t node4_visit(const DScene &sc, int32_t ref, V3 inv, V3 oi, float t
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int sh = 8 * c;
-        const float tnx = __builtin_fmaf((float)((qnx >> sh) & 255u), sx, ox), tfx = __builtin_fmaf((float)((qfx >> sh) & 255u), sx, ox);
-        const float tny = __builtin_fmaf((float)((qny >> sh) & 255u), sy, oy), tfy = __builtin_fmaf((float)((qfy >> sh) & 255u), sy, oy);
-        const float tnz = __builtin_fmaf((float)((qnz >> sh) & 255u), sz, oz), tfz = __builtin_fmaf((float)((qfz >> sh) & 255u), sz, oz);
+        const float tnx = __builtin_fmaf((float)((qnx >> sh) & 255u), sx, oxn), tfx = __builtin_fmaf((float)((qfx >> sh) & 255u), sx, oxf);
+        const float tny = __builtin_fmaf((float)((qny >> sh) & 255u), sy, oyn), tfy = __builtin_fmaf((float)((qfy >> sh) & 255u), sy, oyf);
+        const float tnz = __builtin_fmaf((float)((qnz >> sh) & 255u), sz, ozn), tfz = __builtin_fmaf((float)((qfz >> sh) & 255u), sz, ozf);
         const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, t_min));
         const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best_t));
         const bool hit = tn <= tf * 1.0000004f && rr[c] != RT_BVH_EMPTY;
@@ -738,11 +773,13 @@ RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_
     if (ref == RT_BVH_EMPTY) return;
     V3 inv = box_inv(r.d);
     V3 oi = r.o * inv;
+    const float fat = ray_fat(sc, r);
     uint32_t sp = 0;
     for (;;) {
         while (ref >= 0 && ref != RT_BVH_EMPTY) {
             if (STATS) cnt.node_visits += 1;
-            ref = node4_visit<STATS>(sc, ref, inv, oi, t_min, best.t, stack, sp, cnt);
+            ref = fat > 0.0f ? node4_visit<STATS, false, true>(sc, ref, inv, oi, t_min, best.t, stack, sp, cnt, TopLds{(LdsF4Ptr)0, 0u}, fat)
+                             : node4_visit<STATS>(sc, ref, inv, oi, t_min, best.t, stack, sp, cnt);
         }
         if (ref == RT_BVH_EMPTY) return;
         uint32_t code = (uint32_t)~ref;
@@ -807,154 +844,27 @@ RT_DEV bool finite_f(float x) { return fabsf(x) < INFINITY; }
 
 // The always-list is the reference's flat `world` scan for the slots the BVH does not hold (every leaf of a scene of up to
 // 24 leaves: the Cornell box, Blocks; quadrics anywhere): every slot is tested against every ray with the SAME (t_min, t_max)
-// (hittable_list.rs:39-50).  Most of those slots are rectangles, and their exact test is one correctly rounded division per
-// rectangle and ray (rectangles.rs:22) although a ray inside a closed box can hit one or two of them.  So the scan runs in
-// two phases that change no bit of the result:
-//   1. a conservative pre-test per rectangle (wave-uniform slot index, slot data in scalar registers): the ray parameter
-//      from a reciprocal ESTIMATE (v_rcp_f32, 1 ulp) and the hit point from it, compared against the bounds widened by an
-//      error margin.  A slot it rejects cannot be accepted by the exact test (proof below).  Lanes whose ray could produce
-//      an inf or NaN anywhere in the exact test (a direction component outside [2^-40, 2^40], an origin beyond 2^40) keep
-//      every rectangle as a candidate.
-//   2. each lane runs the UNCHANGED exact test on its own candidates only (per-lane slot index), so the wave iterates
-//      max-over-lanes candidates (2-3 in a closed box) instead of all rectangles; slots of other kinds (spheres, quadrics,
-//      ...) go through the exact test as before, wave-uniform.
-// The fold (`consider`) does not depend on the order candidates arrive in.
-//
-// Error bound of the pre-test (u = 2^-24, E = 2^-19; all quantities finite and normal by the range check, denormal results
-// are covered by the absolute slack 1e-30): exact t = fl(n / d) and estimate t' = fl(n * rcp(d)) with the same n = fl(k - o)
-// differ by |t' - t| <= |t| (2^-23 + 2u) < |t| 2^-21.  Exact a = fl(o_A + fl(t d_A)), estimate a' = fl(fl(t' d_A) + o_A):
-// |a' - a| <= |t d_A| (2^-21 + 4u) + 2u |o_A| < (|fl(t' d_A)| + |o_A|) 2^-20 = eps / 2.  The pre-test rejects on
-// a' + eps < a0 (resp. a' - eps > a1), i.e. only if a < a0 (a > a1), which the exact test rejects too; the rounding of
-// a' +- eps is below eps / 16.  t' (1 + E) + 1e-30 < t_min implies t < t_min likewise (t and t' have the same sign).
-#define RT_FILTER_E 1.9073486328125e-06f          /* 2^-19 */
-#define RT_FILTER_RANGE 1.099511627776e+12f       /* 2^40 */
-
-RT_DEV bool filter_range_ok(const Ray &r) {       // false -> this lane skips the pre-test (every rectangle is a candidate)
-    const float lo = 1.0f / RT_FILTER_RANGE, hi = RT_FILTER_RANGE;
-    const float ax = fabsf(r.d.x), ay = fabsf(r.d.y), az = fabsf(r.d.z);
-    return ax >= lo && ay >= lo && az >= lo && ax <= hi && ay <= hi && az <= hi &&
-           fabsf(r.o.x) <= hi && fabsf(r.o.y) <= hi && fabsf(r.o.z) <= hi;
-}
-
-template <int AX, int A, int B>
-RT_DEV bool rect_maybe_axes(float4 q0, float k, const Ray &r, V3 rcp, float t_min, float t_max) {
-    const float E = RT_FILTER_E;
-    const float t = (k - comp(r.o, AX)) * comp(rcp, AX);
-    const float pa = t * comp(r.d, A), pb = t * comp(r.d, B);
-    const float a = pa + comp(r.o, A), b = pb + comp(r.o, B);
-    const float ea = __builtin_fmaf(fabsf(pa) + fabsf(comp(r.o, A)), E, 1.0e-30f);
-    const float eb = __builtin_fmaf(fabsf(pb) + fabsf(comp(r.o, B)), E, 1.0e-30f);
-    const float et = __builtin_fmaf(fabsf(t), E, 1.0e-30f);
-    const bool out = t + et < t_min || t - et > t_max || a + ea < q0.x || a - ea > q0.y || b + eb < q0.z || b - eb > q0.w;
-    return !out;
-}
-RT_DEV bool rect_maybe(int type, float4 q0, float k, const Ray &r, V3 rcp, float t_min, float t_max) {   // type is wave-uniform here
-    if (!(fabsf(k) <= RT_FILTER_RANGE)) return true;   // a plane that far out: no pre-test
-    if (type == RT_PRIM_XY_RECT) return rect_maybe_axes<2, 0, 1>(q0, k, r, rcp, t_min, t_max);
-    if (type == RT_PRIM_XZ_RECT) return rect_maybe_axes<1, 0, 2>(q0, k, r, rcp, t_min, t_max);
-    return rect_maybe_axes<0, 1, 2>(q0, k, r, rcp, t_min, t_max);
-}
-
-// rect_test_axes with the axes picked per lane: the same operations on the same operands, so the same bits.
-RT_DEV bool rect_test_lane(int type, float4 q0, float k, const Ray &r, float t_min, float t_max, float *t_out) {
-    const bool xy = type == RT_PRIM_XY_RECT, yz = type == RT_PRIM_YZ_RECT;
-    // (the components go through an empty asm first: left alone, the optimiser turns "select between fields of a Ray" into a
-    // dynamically indexed load from a Ray it then has to keep in memory — 28 bytes of LDS per thread)
-    float ox = r.o.x, oy = r.o.y, oz = r.o.z, dx = r.d.x, dy = r.d.y, dz = r.d.z;
-    asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz), "+v"(dx), "+v"(dy), "+v"(dz));
-    const float o_ax = xy ? oz : (yz ? ox : oy), d_ax = xy ? dz : (yz ? dx : dy);
-    const float o_a = yz ? oy : ox, d_a = yz ? dy : dx;
-    const float o_b = xy ? oy : oz, d_b = xy ? dy : dz;
-    const float t = (k - o_ax) / d_ax;
-    if (t < t_min || t > t_max) return false;
-    const float a = o_a + t * d_a;
-    const float b = o_b + t * d_b;
-    if (a < q0.x || a > q0.y || b < q0.z || b > q0.w) return false;
-    *t_out = t;
-    return true;
-}
-
-#ifndef RT_ALWAYS_FILTER
-#define RT_ALWAYS_FILTER 0      // 1 = two-phase scan (conservative pre-test + per-lane exact test); measured SLOWER on MI355X, see DESIGN.md §3
-#endif
+// (hittable_list.rs:39-50).  The slot index is wave-uniform: slot i + 1 is fetched while slot i is tested (through the scalar
+// cache outside the small kernel set, load_slot_uniform), and consecutive slots under one transform (the six sides of a block)
+// share the transformed ray.  (A two-phase scan — a conservative reciprocal-estimate pre-test per rectangle, then the exact test
+// per lane on its own candidates — changed no bit and was slower on MI355X: profiles/r2/experiments/always_filter.patch.)
 template <bool STATS, int EXT = EXT_ALL>
 RT_DEV void always_scan(const DScene &sc, const Ray &r, float t_min, float t_max, int32_t floor_id, Hit &best, Counters &cnt) {
-#if !RT_ALWAYS_FILTER
-    if (sc.always_count) {   // the slot index is wave-uniform: fetch slot i+1 while slot i is tested
-        SlotRec nx = load_slot_uniform<EXT>(sc, sc.always_begin);
-        int frame_xf = -1;   // consecutive slots under one transform (the six sides of a block) share the transformed ray
-        Ray r_frame = r;
-        for (uint32_t i = 0; i < sc.always_count; ++i) {
-            const SlotRec cu = nx;
-            const uint32_t s = sc.always_begin + i;
-            if (i + 1 < sc.always_count) nx = load_slot_uniform<EXT>(sc, s + 1);
-            const int w4 = f2i(cu.meta.x), xf = (w4 >> 8) - 1;   // wave-uniform
-            if (xf != frame_xf) {
-                frame_xf = xf;
-                r_frame = xf < 0 ? r : (type_has_inline_xform(w4 & 15) ? to_object_rec<EXT>(sc, cu.q2, cu.q3, r) : to_object<EXT>(sc, xf, r));
-            }
-            float t; int32_t id;
-            if (slot_hit_rec<STATS, EXT>(sc, s, cu, r, t_min, t_max, &t, &id, cnt, true, r_frame) && id > floor_id) consider(best, t, id, (int32_t)s);
+    if (!sc.always_count) return;
+    SlotRec nx = load_slot_uniform<EXT>(sc, sc.always_begin);
+    int frame_xf = -1;
+    Ray r_frame = r;
+    for (uint32_t i = 0; i < sc.always_count; ++i) {
+        const SlotRec cu = nx;
+        const uint32_t s = sc.always_begin + i;
+        if (i + 1 < sc.always_count) nx = load_slot_uniform<EXT>(sc, s + 1);
+        const int w4 = f2i(cu.meta.x), xf = (w4 >> 8) - 1;   // wave-uniform
+        if (xf != frame_xf) {
+            frame_xf = xf;
+            r_frame = xf < 0 ? r : (type_has_inline_xform(w4 & 15) ? to_object_rec<EXT>(sc, cu.q2, cu.q3, r) : to_object<EXT>(sc, xf, r));
         }
-    }
-    return;
-#endif
-    for (uint32_t c0 = 0; c0 < sc.always_count; c0 += 32u) {      // 32 slots at a time: one mask word
-        const uint32_t cn = sc.always_count - c0 < 32u ? sc.always_count - c0 : 32u, s0 = sc.always_begin + c0;
-        uint32_t cand = 0u;      // per lane: rectangles the exact test may accept
-        uint32_t rects = 0u;     // wave-uniform: which of the cn slots are rectangles
-        bool unfiltered = false; // per lane: the ray is outside the pre-test's range in some frame
-        {
-            SlotRec nx = load_slot(sc, s0);
-            int frame_xf = -2;   // consecutive slots under one transform (the six sides of a block) share the transformed ray
-            Ray rf = r;
-            V3 rcp = v3(0.0f, 0.0f, 0.0f);
-            for (uint32_t i = 0; i < cn; ++i) {      // phase 1; the slot index is wave-uniform: fetch slot i+1 while slot i is tested
-                const SlotRec cu = nx;
-                if (i + 1 < cn) nx = load_slot(sc, s0 + i + 1);
-                const int w4 = f2i(cu.meta.x), type = w4 & 15, xf = (w4 >> 8) - 1;
-                // rectangles, plain or under Translate / RotateY; one under a general Transform stays with the "other kinds"
-                // (its matrices would have to sit in vector registers per lane: 36 of them)
-                if (type < RT_PRIM_XY_RECT || type > RT_PRIM_YZ_RECT || (xf >= 0 && (f2i(cu.q2.x) & 12))) continue;
-                rects |= 1u << i;
-                if (STATS) cnt.prim_tests[type] += 1;
-                if (xf != frame_xf) {
-                    frame_xf = xf;
-                    rf = xf < 0 ? r : to_object_rec<EXT_NONE>(sc, cu.q2, cu.q3, r);
-                    rcp = v3(__builtin_amdgcn_rcpf(rf.d.x), __builtin_amdgcn_rcpf(rf.d.y), __builtin_amdgcn_rcpf(rf.d.z));
-                    unfiltered = unfiltered || !filter_range_ok(rf);
-                }
-                if (rect_maybe(type, cu.q0, cu.meta.w, rf, rcp, t_min, t_max)) cand |= 1u << i;
-            }
-        }
-        if (unfiltered) cand = rects;
-        while (cand != 0u) {     // phase 2, rectangles: every lane takes its own next candidate
-            const uint32_t i = (uint32_t)__builtin_ctz(cand), s = s0 + i;
-            cand &= cand - 1u;
-            const float4 *ps = sc.slots + 4 * (size_t)s;
-            const float4 q0 = ps[0], meta = ps[1];
-            const int w4 = f2i(meta.x), type = w4 & 15, xf = (w4 >> 8) - 1;
-            Ray rf = r;
-            if (xf >= 0) rf = to_object_rec<EXT_NONE>(sc, ps[2], ps[3], r);
-            float t;
-            const int32_t id = f2i(meta.z);
-            if (rect_test_lane(type, q0, meta.w, rf, t_min, t_max, &t) && id > floor_id) consider(best, t, id, (int32_t)s);
-        }
-        uint32_t others = ~rects & (cn == 32u ? 0xffffffffu : (1u << cn) - 1u);      // wave-uniform
-        int frame_xf = -2;
-        Ray rf = r;
-        while (others != 0u) {   // phase 2, everything else: the exact test, wave-uniform slot index as before
-            const uint32_t i = (uint32_t)__builtin_ctz(others), s = s0 + i;
-            others &= others - 1u;
-            const SlotRec cu = load_slot(sc, s);
-            const int w4 = f2i(cu.meta.x), xf = (w4 >> 8) - 1;
-            if (xf != frame_xf) {
-                frame_xf = xf;
-                rf = xf < 0 ? r : (type_has_inline_xform(w4 & 15) ? to_object_rec<EXT>(sc, cu.q2, cu.q3, r) : to_object<EXT>(sc, xf, r));
-            }
-            float t; int32_t id;
-            if (slot_hit_rec<STATS, EXT>(sc, s, cu, r, t_min, t_max, &t, &id, cnt, true, rf) && id > floor_id) consider(best, t, id, (int32_t)s);
-        }
+        float t; int32_t id;
+        if (slot_hit_rec<STATS, EXT>(sc, s, cu, r, t_min, t_max, &t, &id, cnt, true, r_frame) && id > floor_id) consider(best, t, id, (int32_t)s);
     }
 }
 
@@ -1069,6 +979,7 @@ struct Trav {
     Hit best;
     int32_t floor_id;   // id of the last NaN candidate (see closest_hit), -1 if none
     V3 inv, oi;
+    float fat;          // ray_fat(): how much every box is grown for this ray (0: an ordinary ray)
 };
 
 // world.hit() up to the point where the BVH walk starts.  Returns true if there is a walk to do.
@@ -1113,6 +1024,7 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
     if (sc.root_ref == RT_BVH_EMPTY) { RG_END(RG_B_REST); return false; }
     tv.inv = box_inv(r.d);
     tv.oi = r.o * tv.inv;
+    tv.fat = ray_fat(sc, r);
     tv.ref = sc.root_ref;
     RG_END(RG_B_REST);
     return true;
@@ -1121,7 +1033,8 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
 template <bool STATS, bool LT = false>
 RT_DEV void trav_node_step(const DScene &sc, float t_min, Trav &tv, const Stack &stack, Counters &cnt, const TopLds &top = TopLds{(LdsF4Ptr)0, 0u}) {
     if (STATS) cnt.node_visits += 1;
-    tv.ref = node4_visit<STATS, LT>(sc, tv.ref, tv.inv, tv.oi, t_min, tv.best.t, stack, tv.sp, cnt, top);
+    if (RT_FAR_WALK && tv.fat > 0.0f) tv.ref = node4_visit<STATS, LT, true>(sc, tv.ref, tv.inv, tv.oi, t_min, tv.best.t, stack, tv.sp, cnt, top, tv.fat);
+    else tv.ref = node4_visit<STATS, LT>(sc, tv.ref, tv.inv, tv.oi, t_min, tv.best.t, stack, tv.sp, cnt, top);
 }
 
 template <bool STATS, int EXT>

@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
     r.o = v3(0.0f, 0.0f, 0.0f); r.d = r.o; r.time = 0.0f;
     Trav tv;
     tv.ref = RT_BVH_EMPTY; tv.sp = 0; tv.best.t = 0.0f; tv.best.id = -1; tv.best.slot = 0; tv.floor_id = -1;
-    tv.inv = r.o; tv.oi = r.o;
+    tv.inv = r.o; tv.oi = r.o; tv.fat = 0.0f;
     const float T_MIN = 0.001f;
     RG_BEGIN(RG_TRAV_ALL);
     uint32_t dbg_turns = 0;
@@ -385,6 +385,7 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
                         tv.best.t = h.x; tv.best.id = f2i(h.y); tv.best.slot = f2i(h.z); tv.floor_id = f2i(h.w);
                         tv.inv = box_inv(r.d);
                         tv.oi = r.o * tv.inv;
+                        tv.fat = ray_fat(sc, r);
                         tv.sp = 0;
                         tv.ref = root_ref;
                     }
@@ -624,7 +625,7 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
         p.pixel = 0; p.sample = 0; p.item = 0; p.rng.state = 0; p.rng.inc = 1;
         Trav tv;
         tv.ref = RT_BVH_EMPTY; tv.sp = 0; tv.best.t = 0.0f; tv.best.id = -1; tv.best.slot = 0; tv.floor_id = -1;
-        tv.inv = p.ps.ray.o; tv.oi = p.ps.ray.o;
+        tv.inv = p.ps.ray.o; tv.oi = p.ps.ray.o; tv.fat = 0.0f;
         if (lane < set_lanes && off + lane < n) {
             const float4 d = q.ray_d[i];
             const uint32_t flags = __float_as_uint(d.w);
@@ -646,6 +647,7 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
                     const Ray &r = p.ps.ray;
                     tv.inv = box_inv(r.d);
                     tv.oi = r.o * tv.inv;
+                    tv.fat = ray_fat(sc, r);
                     tv.sp = 0;
                     tv.ref = sc.root_ref;
                 }

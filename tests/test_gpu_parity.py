@@ -172,6 +172,34 @@ def test_other_projections_match_the_oracle(rt, gpu, projection, name):
         assert rays[0, 0] == 0 and rays[-1, -1] == 0 and rays[rays.shape[0] // 2, rays.shape[1] // 2] > 0
 
 
+def test_rays_from_far_away_see_what_the_flat_list_sees(rt, gpu):
+    """sphere.rs:46-66 in f32 accepts small spheres thousands of radii away from a ray's origin (cancellation: DESIGN.md section 3,
+    tests/test_oracle_kat.py::test_cancellation_false_positive); the reference's flat `world` takes those hits, a walk that culls
+    by the spheres' boxes would not.  Rays that start beyond rt_scene_desc::far_limit walk the tree with every box grown by the
+    distance at which that can happen (rt_kernels.h, ray_fat): the known ray gets the oracle's hit from rt_trace_first_hit, and
+    the Orthographic view whose plane dips into the r = 1000 ground sphere (the default look_from) traces the oracle's paths,
+    pixel for pixel."""
+    scene, params, camera, sampler = rt.configs.build("C1", image_width=96, samples_per_pixel=4)
+    flat = scene.flatten()
+    assert flat.desc.far_limit == pytest.approx(0.2 * 1024)          # RandomWorld is a flat list; its smallest spheres have r = 0.2
+    gpu.upload_scene(flat)
+    gpu.upload_sampler(sampler)
+    ray = np.array([[-647.327393, -1432.85925, -627.37561, 909.112427, 1986.85925, 878.007812, 0.662694097]], np.float32).T.copy()
+    oracle = O.OracleScene(scene)
+    want = oracle.first_hit(ray)
+    got = gpu.trace_first_hit(ray)
+    assert want[0][0] != 0xFFFFFFFF and got[0][0] == want[0][0] and got[1][0] == want[1][0]
+    near = ray.copy(); near[0:6] /= 2048.0                            # the same line at a human scale: the walk, and no hit
+    assert gpu.trace_first_hit(near)[0][0] == oracle.first_hit(near)[0][0]
+    params = params.replace(projection=1)
+    assert params.projection_name == "Orthographic"
+    camera = params.camera()
+    got, st, rays = gpu.render(params, camera, stats=True, want_pixel_rays=True)
+    want, n_rays, want_rays = oracle.render(params, camera, sampler, want_pixel_rays=True)
+    assert np.array_equal(rays, want_rays) and st["rays"] == n_rays
+    np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=2e-4, atol=1e-6)
+
+
 def quadric_playground(rt):
     """Every quadric kind, partial sweeps, FlipFace on either side of a Transform, metal and glass quadrics (so that
     paths leave the surfaces at grazing angles) next to 31 spheres that go through the BVH."""

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 @contextlib.contextmanager
 def knobs(**kv):
-    """The library reads its tuning knobs from the environment on every rt_render call."""
+    """The library reads its tuning knobs from the environment on every rt_render call — while RT_KNOBS is set there too."""
+    kv = dict(kv, RT_KNOBS=1)
     old = {k: os.environ.get(k) for k in kv}
     os.environ.update({k: str(v) for k, v in kv.items()})
     try:

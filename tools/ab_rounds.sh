@@ -8,7 +8,7 @@ for ((r = 0; r < ROUNDS; ++r)); do
     IFS='|' read -ra arr <<< "$WLS"
     for wl in "${arr[@]}"; do
       set -- $wl
-      env $setting timeout -k 10 300 python3 bench.py --workload $1 --spp $2 --steps $3 --warmup 1 --no-cpu --no-sub > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err || { echo "$setting $wl FAILED"; tail -3 gpurun_out/ab_tmp.err; exit 1; }
+      env RT_KNOBS=1 $setting timeout -k 10 300 python3 bench.py --workload $1 --spp $2 --steps $3 --warmup 1 --no-cpu --no-sub > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err || { echo "$setting $wl FAILED"; tail -3 gpurun_out/ab_tmp.err; exit 1; }
       python3 -c "
 import json
 d=json.loads(open('gpurun_out/ab_tmp.json').read().strip().splitlines()[-1])
