@@ -69,7 +69,7 @@ def kernel_busy_ms(name, base_spp):
         return None, None
     with open(base + "_ktrace_bench.json") as f:
         line = json.loads(f.read().strip().splitlines()[-1])
-    frames = line["steps"] + line["warmup"]
+    frames = line.get("frames_rendered", line["steps"] + line["warmup"])
     busy = {}
     with open(base + "_kernel_stats.csv") as f:
         for r in csv.DictReader(f):
@@ -79,6 +79,14 @@ def kernel_busy_ms(name, base_spp):
                     # (the fold kernel is not a template: its rows hold the counting run's frame too)
                     per = frames + 1 if k == "fold" else frames
                     busy[k] = busy.get(k, 0.0) + float(r["TotalDurationNs"]) / 1e6 / per
+    # ... and the time each kernel needs when it has the chip to itself: SQ_BUSY_CYCLES of the PMC passes, whose dispatches run one
+    # at a time (tools/pmc_report.py: busy_ms)
+    if os.path.exists(base + "_pmc.json"):
+        with open(base + "_pmc.json") as f:
+            for n, k in json.load(f)["kernels"].items():
+                for key in KERNELS + ("fold",):
+                    if "wf_%s_kernel" % key in n and k.get("busy_ms"):
+                        busy[key + "_alone"] = k["busy_ms"]
     return busy, os.path.relpath(base + "_kernel_stats.csv", ROOT)
 
 
@@ -175,7 +183,8 @@ class Bench:
         comm_stream = torch.cuda.Stream(device=dev) if self.comm is not None else None
         rendered = [torch.cuda.Event() for _ in accs]
         reduced = [torch.cuda.Event() for _ in accs]
-        for k in range(min(warmup, 2) * n_fl if args.frames > 1 else 0):     # untimed: the second workspace and its streams come into being
+        extra_warmup = min(warmup, 2) * n_fl if args.frames > 1 else 0
+        for k in range(extra_warmup):     # untimed: the second workspace and its streams come into being
             with torch.cuda.stream(streams[k % n_fl]):
                 accs[k % n_fl].zero_()
                 gpu.render_device(params, camera, accs[k % n_fl].data_ptr(), streams[k % n_fl].cuda_stream, spp_begin=spp_begin, spp_count=spp_count)
@@ -238,12 +247,15 @@ class Bench:
                 for k in KERNELS:
                     f_k = algorithmic_flops(st["kernels"][k])
                     b = busy.get(k)
+                    alone = busy.get(k + "_alone")
                     per_kernel[k] = {"flops": f_k, "busy_ms": b, "tflops": (f_k / (b * 1e-3) / 1e12) if b else None,
-                                     "frac": (f_k / (b * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS) if b else None}
+                                     "frac": (f_k / (b * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS) if b else None,
+                                     "alone_ms": alone, "frac_alone": (f_k / (alone * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS) if alone else None}
                 per_kernel["fold"] = {"flops": 3.0 * total_paths, "busy_ms": busy.get("fold"), "tflops": None, "frac": None}
         out = {
             "value": total_rays * steps / elapsed / 1e6, "unit": "Mrays/s", "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3,
+            "frames_rendered": warmup + extra_warmup + steps,      # by the timed kernels (+ one by the counting variant)
             "config": {"workload": "%s %s %dx%d, %d spp per GPU (%d total), depth %d" % (
                 name, rt.configs.WORKLOADS[name]["scene"], W, H, spp_count, total_spp, params.max_ray_depth),
                 "sharding": ("sample ranges per GPU + RCCL reduce to rank 0, overlapped with the next frame's render" + (", fixed frame" if args.strong else "")) if self.world > 1 else "single GPU",
@@ -266,7 +278,7 @@ class Bench:
                          "kernels": per_kernel, "kernels_busy_from": busy_src,
                          "note": "no dense contraction -> FP32 vector roofline (SURVEY.md 8d); flops = work counters x per-unit constants; "
                                  "kernel_ms = device time per call: HIP events on the caller's streams from the first call's start to the last one's end, over the calls (the pipelines' streams fork from and join the caller's; with two frames in flight the end of one call runs beside the start of the next, frame_ms = start to end of one call); "
-                                 "kernels = per kernel: counters of that kernel (rt_last_kernel_stats) x the same constants over its busy time per frame in the committed kernel trace; "
+                                 "kernels = per kernel: counters of that kernel (rt_last_kernel_stats) x the same constants over its busy time per frame in the committed kernel trace (busy_ms: the sum of its launches' durations, during which it shares the chip with the other pipeline's kernels) and over the time it needs alone (alone_ms: SQ_BUSY_CYCLES of the PMC passes, whose dispatches run one at a time); "
                                  "traffic = FETCH_SIZE*2 + WRITE_SIZE bytes per step over all kernels, from " + (traffic_src or "n/a")},
         }
         if cpu:

@@ -29,7 +29,7 @@ constexpr int kFrames = 2;     // renders in flight per context: each has a work
 // Workspace of one render in flight.  rt_render returns once a frame's last kernels are queued; the frame's workspace is
 // taken again by the render after next, which first waits for `done` (settle()).
 struct WfSpace {
-    void *pool = nullptr;      size_t pool_entries = 0;         // 2 buffers x entries x 72 B per pipeline
+    void *pool = nullptr;      size_t pool_entries = 0;  int pool_pipes = 0;   // 2 buffers x entries x 72 B for each of pool_pipes pipelines
     float4 *samples = nullptr; size_t samples_entries = 0;
     WfCounters *ctr = nullptr;                                  // per pipeline: ring + status words behind it
     StackEntry *ovf = nullptr; size_t ovf_entries = 0;          // traversal stack overflow (entries beyond the LDS part)
@@ -282,10 +282,12 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     }
     const size_t per_pipe_items = (need_samples + n_pipes - 1) / n_pipes;
     size_t pool = per_pipe_items < pool_want ? (per_pipe_items + shard_q - 1) / shard_q * shard_q : pool_want;
-    if (S.pool_entries < pool) {
-        if (S.pool) { (void)hipDeviceSynchronize(); (void)hipFree(S.pool); S.pool = nullptr; S.pool_entries = 0; }
-        HIP_TRY(ctx, hipMalloc(&S.pool, pool * 2 * kEntryBytes * kMaxPipes));
-        S.pool_entries = pool;
+    if (S.pool_entries < pool || S.pool_pipes < n_pipes) {   // two buffers of the largest pool seen for each of the most pipelines seen
+        const size_t entries = pool > S.pool_entries ? pool : S.pool_entries;
+        const int pipes = n_pipes > S.pool_pipes ? n_pipes : S.pool_pipes;
+        if (S.pool) { (void)hipDeviceSynchronize(); (void)hipFree(S.pool); S.pool = nullptr; S.pool_entries = 0; S.pool_pipes = 0; }
+        HIP_TRY(ctx, hipMalloc(&S.pool, entries * 2 * kEntryBytes * (size_t)pipes));
+        S.pool_entries = entries; S.pool_pipes = pipes;
     }
     // counters, status words, streams and events: made when first needed and kept (what exists after a failure is used by the
     // next call or released by rt_destroy).  (Measured and dropped, profiles/r3/ab_frames_in_flight.txt: a second stream of the

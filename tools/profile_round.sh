@@ -7,7 +7,7 @@ for wl in "${arr[@]}"; do
   set -- $wl
   n=$(echo $1 | tr A-Z a-z)
   tag=${n}_$2
-  bash tools/ktrace.sh $tag $1 $2 --no-sub > gpurun_out/prof_${n}_${2}spp_ktrace.txt 2>&1 || { echo "ktrace $wl failed"; tail -3 gpurun_out/kt_$tag.err; exit 1; }
+  bash tools/ktrace.sh $tag $1 $2 --no-sub --frames 1 > gpurun_out/prof_${n}_${2}spp_ktrace.txt 2>&1 || { echo "ktrace $wl failed"; tail -3 gpurun_out/kt_$tag.err; exit 1; }
   cp gpurun_out/kt_${tag}_kernel_stats.csv gpurun_out/prof_${n}_${2}spp_kernel_stats.csv
   cp gpurun_out/kt_${tag}.json gpurun_out/prof_${n}_${2}spp_ktrace_bench.json
   bash tools/pmc.sh $tag $1 $2 || { echo "pmc $wl failed"; exit 1; }
