@@ -835,15 +835,13 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
     {   // the top of the tree in breadth-first order (DScene::top_order / top_child), for the walk that keeps it in LDS
         std::vector<uint32_t> order, child;
         if (!device_build && s->bvh_root_ref != RT_BVH_EMPTY && s->bvh_root_ref >= 0) {
-            std::vector<uint32_t> place(s->n_bvh_nodes, 0xffffffffu);
             order.push_back((uint32_t)s->bvh_root_ref);
-            place[(size_t)s->bvh_root_ref] = 0;
             for (size_t k = 0; k < order.size(); ++k) {       // (the queue is the order itself)
                 int32_t refs[4];
                 memcpy(refs, &s->bvh_nodes[(size_t)order[k] * RT_NODE_FLOATS + 12], 16);
                 for (int32_t r : refs) {
                     uint32_t at = 0xffffffffu;
-                    if (r >= 0 && r != RT_BVH_EMPTY && order.size() < kMaxTopNodes) { at = (uint32_t)order.size(); place[(size_t)r] = at; order.push_back((uint32_t)r); }
+                    if (r >= 0 && r != RT_BVH_EMPTY && order.size() < kMaxTopNodes) { at = (uint32_t)order.size(); order.push_back((uint32_t)r); }
                     child.push_back(at);
                 }
             }
@@ -1120,7 +1118,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *out_rgba_sum, rt_st
     {
         int rc = p->collect_stats ? render_wavefront<true>(ctx, a, p, d_out, d_rays, stream) : render_wavefront<false>(ctx, a, p, d_out, d_rays, stream);
         if (rc != RT_OK) {
-            (void)hipStreamSynchronize(stream);
+            (void)hipDeviceSynchronize();     // the pipelines' streams may hold work of the call that failed: nothing of it outlives the call
             if (tmp_out) (void)hipFree(tmp_out);
             if (tmp_rays) (void)hipFree(tmp_rays);
             return rc;

@@ -313,3 +313,41 @@ def test_a_boundary_medium_needs_an_isotropic_material_whose_texture_reads_no_uv
     b.upload_scene(flat)                                        # the context is still usable
     b.upload_sampler(sampler)
     assert np.isfinite(b.render(params, camera)[0]).all()
+
+
+def test_stream_calls_check_their_arguments(rt, ctx):
+    b, *_ = ctx
+    L = b._L
+    assert L.rt_stream_create(None, None) == RT_E_INVALID
+    st, msg = status_and_text(b, L.rt_stream_create(b._h, None))
+    assert st == RT_E_INVALID and "out is NULL" in msg
+    s = b.stream_create()
+    assert s
+    assert L.rt_stream_wait(b._h, s, s) == 0 and L.rt_stream_wait(b._h, s, None) == 0 and L.rt_stream_wait(b._h, None, s) == 0
+    assert L.rt_stream_wait(None, s, None) == RT_E_INVALID
+    assert L.rt_stream_destroy(b._h, None) == 0 and L.rt_stream_destroy(None, s) == RT_E_INVALID
+    b.stream_destroy(s)
+
+
+def test_tuning_knobs_are_ignored_unless_RT_KNOBS_is_set(rt, ctx):
+    # a 1 MB sample buffer cannot hold one sample of this window: with the knobs on the render is refused, without RT_KNOBS the
+    # variable is not even looked at (a product run is what the defaults say)
+    import os
+    b, flat, params, camera, sampler = ctx
+    b.upload_scene(flat)
+    b.upload_sampler(sampler)
+    want, _ = b.render(params, camera, width=512, height=512)
+    old = {k: os.environ.pop(k, None) for k in ("RT_KNOBS", "RT_WF_SAMPLES_MB")}
+    try:
+        os.environ["RT_WF_SAMPLES_MB"] = "1"
+        got, _ = b.render(params, camera, width=512, height=512)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        os.environ["RT_KNOBS"] = "1"
+        with pytest.raises(rt._ffi.RtError) as e:
+            b.render(params, camera, width=512, height=512)
+        assert e.value.status == -4 and "does not fit the sample buffer" in str(e.value)      # RT_E_OOM
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
