@@ -93,7 +93,7 @@ enum rt_prim_type {
  * xform     [0] i: bit0 rotate-y, bit1 translate  [1] sin [2] cos [3..5] offset
  *           meaning Translate(RotateY(obj)) (transform.rs:9-153);
  *           bit2 = general Transform (transform.rs:155-213), then [1] i: index into `matrices`;
- *           [0] = 8: a chain, [1] i: first [2] i: count (2..8) = that many consecutive records of the kinds above,
+ *           [0] = 8: a chain, [1] i: first [2] i: count (2..64) = that many consecutive records of the kinds above,
  *           outermost wrapper first: any other nesting of the three wrappers (each hit() hands its ray to its child)
  * matrix    [0..11] world2object rows 0..2 (a00 a01 a02 a03 | a10 ..)  [12..23] obj2world  [24..35] normal2world
  *           (= adjoint(world2object) transposed, transform.rs:171); last rows are 0,0,0,1 and not stored

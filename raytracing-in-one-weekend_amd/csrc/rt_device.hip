@@ -704,10 +704,10 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
             auto matrix_ok = [&](int32_t mi) { return mi >= 0 && (uint32_t)mi < s->n_matrices && s->matrices; };
             if ((flags & 4) && !matrix_ok(m)) return fail(ctx, RT_E_INVALID, "slot %u: matrix out of range", i);
             chain = (flags & 8) != 0;
-            if (chain) {                     // a run of 2..8 plain records
+            if (chain) {                     // a run of 2..64 plain records
                 int32_t count;
                 memcpy(&count, &s->xforms[(size_t)xf * RT_REC_FLOATS + 2], 4);
-                if (flags != 8 || m < 0 || count < 2 || count > 8 || (uint64_t)m + (uint64_t)count > s->n_xforms)
+                if (flags != 8 || m < 0 || count < 2 || count > 64 || (uint64_t)m + (uint64_t)count > s->n_xforms)
                     return fail(ctx, RT_E_INVALID, "slot %u: xform chain outside the xform array", i);
                 for (int32_t k = m; k < m + count; ++k) {
                     int32_t f2, m2;

@@ -94,7 +94,7 @@ struct Flattener {
     // their medium's record; they take no primitive id (rt_scene_graph.h) and appear in no tree or list
     std::vector<Slot> boundary;
     bool boundary_mode = false;
-    static constexpr size_t kMaxOps = 8;   // xform records per chain (rt_api.h)
+    static constexpr size_t kMaxOps = 64;  // xform records per chain (rt_api.h; the walk itself stops at 64 levels of nesting)
 
     bool fail(const std::string &m) {
         if (err.empty()) err = m;
@@ -263,7 +263,7 @@ struct Flattener {
         }
         case RTG_TRANSFORM: {
             if (n.child_count != 1) return fail("Transform needs one child");
-            if (w.ops.size() >= kMaxOps) return fail("more than 8 nested Translate / RotateY / Transform wrappers");
+            if (w.ops.size() >= kMaxOps) return fail("more than 64 nested Translate / RotateY / Transform wrappers");
             M4 o2w = m4_identity(), w2o;
             memcpy(o2w.a, n.f, 12 * sizeof(float));
             if (!m4_invert(o2w, &w2o)) return fail("Matrix is not invertible");          // transform.rs:166
@@ -286,7 +286,7 @@ struct Flattener {
         case RTG_TRANSLATE:
             if (n.child_count != 1) return fail("Translate needs one child");
         {
-            if (w.ops.size() >= kMaxOps) return fail("more than 8 nested Translate / RotateY / Transform wrappers");
+            if (w.ops.size() >= kMaxOps) return fail("more than 64 nested Translate / RotateY / Transform wrappers");
             WrapOp op;
             op.has_trans = true;
             op.off[0] = n.f[0]; op.off[1] = n.f[1]; op.off[2] = n.f[2];
@@ -299,7 +299,7 @@ struct Flattener {
             // directly under a Translate: that Translate's op takes the rotation too (one record for Translate(RotateY(.)))
             const bool joins = !w.ops.empty() && w.ops.back().has_trans && !w.ops.back().has_rot && w.ops.back().matrix < 0;
             if (!joins) {
-                if (w.ops.size() >= kMaxOps) return fail("more than 8 nested Translate / RotateY / Transform wrappers");
+                if (w.ops.size() >= kMaxOps) return fail("more than 64 nested Translate / RotateY / Transform wrappers");
                 w.ops.push_back(WrapOp{});
             }
             WrapOp &op = w.ops.back();

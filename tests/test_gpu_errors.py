@@ -171,7 +171,7 @@ def test_bad_chain_and_light_list_records_are_refused(rt, ctx):
         return d
 
     cases = [
-        (xf(chain, 2, 9), RT_E_INVALID, "xform chain"),                    # more than 8 records
+        (xf(chain, 2, 65), RT_E_INVALID, "xform chain"),                   # more than 64 records
         (xf(chain, 2, int(d0.n_xforms)), RT_E_INVALID, "xform chain"),     # (would also run past the array)
         (xf(chain, 1, -1), RT_E_INVALID, "xform chain"),
         (xf(int(x[chain, 1]), 0, 8), RT_E_INVALID, "not a plain record"),  # a chain inside a chain

@@ -344,6 +344,15 @@ def nested_wrappers_scene(rt, many):
     objs.append(s.rotate_y(s.translate(s.triangle_mesh(verts, idx, node, None, grey), (4.0, 0.2, 1.0)), 20.0))
     quarter = np.array([[1, 0, 0, 1.0], [0, 0, -1, 1.0], [0, 1, 0, -4.0], [0, 0, 0, 1]], np.float32)
     objs.append(s.translate(s.transform(s.cylinder(0.5, -0.8, 0.8, 2.0 * np.pi, metal), quarter), (0.0, 0.3, 0.0)))     # T(M(quadric))
+    deep = s.sphere((0, 0.5, 0), 0.5, metal)  # twelve wrappers around one sphere: T R T M R T T R M T R T (a chain of eleven records)
+    for k, kind in enumerate("TRTMRTTRMTRT"):
+        if kind == "T":
+            deep = s.translate(deep, (-0.6 + 0.05 * k, 0.02 * k, 0.35))
+        elif kind == "R":
+            deep = s.rotate_y(deep, 7.0 + 3.0 * k)
+        else:
+            deep = s.transform(deep, scale if k == 3 else shear)
+    objs.append(deep)
     for i in range(40 if many else 0):       # enough leaves for a real tree, each under a chain of its own
         pos = (float(rng.uniform(-9, 9)), 0.0, float(rng.uniform(-9, 9)))
         inner = s.sphere((0, 0.3, 0), 0.3, s.lambertian(s.solid(*rng.uniform(0.2, 0.9, 3).tolist()))) if i % 2 else block(grey)
@@ -374,7 +383,7 @@ def test_wrappers_nested_in_any_order(rt, gpu, many):
     assert exact
     hit = g[0] != 0xFFFFFFFF
     seen = set(g[0][hit].tolist())
-    assert {7, 20, 27, 29, 32} <= seen and seen & {30, 31}, "both spheres' kinds, the moving sphere, a triangle and the cylinder must be seen"
+    assert {7, 20, 27, 29, 32, 33} <= seen and seen & {30, 31}, "both spheres' kinds, the moving sphere, a triangle, the cylinder and the sphere under twelve wrappers must be seen"
     _, exact = check_first_hit(gpu, oracle, bounce_rays(rays, g[1], g[2], hit))
     assert exact
     img, _, st = compare_images(rt, gpu, oracle, params, camera, sampler)

@@ -322,7 +322,12 @@ def test_any_wrapper_nesting_flattens_to_chain_records(rt):
     for _ in range(9):
         deep = s.translate(deep, (1, 0, 0))
     s.set_roots(s.hittable_list([deep]), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
-    with pytest.raises(rt.RtError) as e:                                            # at most 8 records per chain
+    x9 = s.flatten().xforms()                                                       # nine wrappers: one chain of nine records
+    assert (x9[:, 0].view(np.int32) == 8).sum() == 1 and x9[x9[:, 0].view(np.int32) == 8][0].view(np.int32)[2] == 9
+    for _ in range(60):
+        deep = s.translate(deep, (1, 0, 0))
+    s.set_roots(s.hittable_list([deep]), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
+    with pytest.raises(rt.RtError) as e:                                            # at most 64 levels of nesting
         s.flatten()
     assert e.value.status == -5
     s = rt.host.Scene()
