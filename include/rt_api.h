@@ -98,9 +98,12 @@ enum rt_prim_type {
  * matrix    [0..11] world2object rows 0..2 (a00 a01 a02 a03 | a10 ..)  [12..23] obj2world  [24..35] normal2world
  *           (= adjoint(world2object) transposed, transform.rs:171); last rows are 0,0,0,1 and not stored
  * medium    [0..3] boundary sphere c,r  [4] neg_inv_density  [5] i: material  [6] i: prim id  [7] i: 0
- *           or, for any other boundary (a Block / rectangle / sphere under Translate / RotateY): [7] i: 1 and
+ *           or, for any other boundary (a Block / rectangle / sphere under any nesting of Translate / RotateY / Transform) and for a
+ *           medium that is itself under such wrappers: [7] i: 1 and
  *           [0] i: first boundary slot  [1] i: number of boundary slots — slots behind the always-list that no tree or
- *           list refers to (primitive id -1); boundary.hit() is the list fold over them (constant_medium.rs:52-58)
+ *           list refers to (primitive id -1); boundary.hit() is the list fold over them (constant_medium.rs:52-58).
+ *           [2] i: 1 + the xform record of the medium's OWN wrappers (0: none); the boundary slots' records then begin with
+ *           the same wrappers, and the medium measures the ray and makes its hit point in their frame (constant_medium.rs:76-93)
  * light     [0] i: rt_prim_type (sphere, moving sphere or rect)  [1..5] q0 (+k for rects);  type 255 = an object that
  *           keeps the trait defaults of hittable.rs:47-53 (pdf_value 0, random = unit_x).  Moving sphere (objects/sphere.rs:204-226):
  *           [1..3] center(0), where pdf_value tests the ray  [4] radius  [5..7] center(time1) - center(time0), what random aims at

@@ -720,7 +720,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         const bool in_always = i >= s->always_begin && i - s->always_begin < s->always_count;
         // quadrics may accept hits below t_min (cone.rs:61-65): the traversal kernels do not carry their code
         if (type >= RT_PRIM_CYLINDER && !in_always) return fail(ctx, RT_E_INVALID, "slot %u: quadrics must be in the always-list", i);
-        general_in_bvh |= general && !in_always;
+        general_in_bvh |= general && i < s->always_begin;      // (slots behind the always-list are media boundaries: no tree refers to them)
         if (general) need |= EXT_XFORM;
         if (chain) need |= EXT_CHAIN;
         if (type >= RT_PRIM_CYLINDER) need |= EXT_QUADRICS;
@@ -788,17 +788,25 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *s) {
         if (kind != 1) return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "medium %u: boundary kind %d", i, kind);
         memcpy(&first, &s->media[i * RT_REC_FLOATS], 4);
         memcpy(&count, &s->media[i * RT_REC_FLOATS + 1], 4);
-        // boundary slots: behind the always-list, plain spheres / rectangles (Translate / RotateY allowed), solid phase function
+        // boundary slots: behind the always-list, spheres / rectangles under any record (checked with the other slots above), solid
+        // phase function; [2] = 1 + the record of the medium's own wrappers
+        int32_t outer;
+        memcpy(&outer, &s->media[i * RT_REC_FLOATS + 2], 4);
+        if (outer < 0 || (uint32_t)outer > s->n_xforms) return fail(ctx, RT_E_INVALID, "medium %u: xform out of range", i);
+        if (outer > 0) {
+            int32_t flags;
+            memcpy(&flags, &s->xforms[(size_t)(outer - 1) * RT_REC_FLOATS], 4);
+            if (flags & 4) need |= EXT_XFORM;
+            if (flags & 8) need |= EXT_CHAIN | EXT_XFORM;
+        }
         if (first < 0 || count < 1 || count > 64 || (uint64_t)first < (uint64_t)s->always_begin + s->always_count || (uint64_t)first + (uint64_t)count > s->n_slots)
             return fail(ctx, RT_E_INVALID, "medium %u: boundary slots [%d, %d) outside the slot array's tail", i, first, first + count);
         for (int32_t k = first; k < first + count; ++k) {
             int32_t w4;
             memcpy(&w4, &s->slots[(size_t)k * RT_SLOT_FLOATS + 4], 4);
-            const int type = w4 & 15, xf = (w4 >> 8) - 1;
-            int32_t flags = 0;
-            if (xf >= 0) memcpy(&flags, &s->xforms[(size_t)xf * RT_REC_FLOATS], 4);
-            if (!(type == RT_PRIM_SPHERE || (type >= RT_PRIM_XY_RECT && type <= RT_PRIM_YZ_RECT)) || (flags & 12))
-                return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "medium %u: boundary slot %d is not a sphere or rectangle under Translate / RotateY", i, k);
+            const int type = w4 & 15;
+            if (!(type == RT_PRIM_SPHERE || (type >= RT_PRIM_XY_RECT && type <= RT_PRIM_YZ_RECT)))
+                return fail(ctx, RT_E_UNSUPPORTED_PRIMITIVE, "medium %u: boundary slot %d is not a sphere or rectangle", i, k);
         }
         // the phase function's texture: an Isotropic material (the one kind ConstantMedium::new makes, constant_medium.rs:22-38; its
         // texture index was range-checked above) whose texture reads no u, v — the kernels keep no u, v of a boundary slot's hit.  The

@@ -318,42 +318,45 @@ struct Flattener {
             return true;
         case RTG_CONSTANT_MEDIUM: {
             if (n.child_count != 1) return fail("ConstantMedium needs one boundary");
-            if (!w.ops.empty() || w.flip) return fail("ConstantMedium under a wrapper is not supported");
+            // (a FlipFace around a medium turns its record's front_face, which Isotropic — the one material a medium has — never reads)
             const rtg_node &b = g->nodes[ch[0]];
-            if (b.type == RTG_SPHERE) {
+            if (b.type == RTG_SPHERE && w.ops.empty()) {
                 float rec[RT_REC_FLOATS] = {b.f[0], b.f[1], b.f[2], b.f[3], -1.0f / n.f[0] /* constant_medium.rs:24 */,
                                             i2f(n.material), i2f((int32_t)next_id++), 0.0f};
                 out->media.insert(out->media.end(), rec, rec + RT_REC_FLOATS);
                 return true;
             }
             // any other boundary (constant_medium.rs:52-58 takes a Hittable; scene_cornell_box_smoke, main.rs:642-680, uses
-            // Translate(RotateY(Block))): wrappers over ONE Block / rectangle / sphere.  Its leaves become boundary slots that the
-            // medium's record points at; boundary.hit() is then the list fold over them (block.rs:111-113, hittable_list.rs:39-50).
+            // Translate(RotateY(Block))), and any medium under wrappers of its own: the boundary is ONE Block / rectangle / sphere
+            // under any nesting of Translate / RotateY / Transform / FlipFace.  Its leaves become boundary slots that the medium's
+            // record points at — each under the medium's wrappers followed by its own, so boundary.hit() is the list fold over
+            // them for the ray as rt_render has it (block.rs:111-113, hittable_list.rs:39-50; t is the same in every frame) —
+            // and the record names the medium's own wrappers, in whose frame ConstantMedium::hit measures the ray's length and
+            // makes its hit point (constant_medium.rs:76-93).
             {
                 int32_t leaf = ch[0];
-                for (int d = 0; d < 8; ++d) {
+                for (int d = 0; d < 64; ++d) {
                     const rtg_node &k = g->nodes[leaf];
-                    if (k.type == RTG_TRANSLATE || k.type == RTG_ROTATE_Y || k.type == RTG_FLIP_FACE) { if (k.child_count != 1) return fail("wrapper needs one child"); leaf = g->children[k.child_begin]; }
-                    else break;
+                    if (k.type == RTG_TRANSLATE || k.type == RTG_ROTATE_Y || k.type == RTG_FLIP_FACE || k.type == RTG_TRANSFORM) {
+                        if (k.child_count != 1) return fail("wrapper needs one child");
+                        leaf = g->children[k.child_begin];
+                    } else break;
                 }
                 const int lt = g->nodes[leaf].type;
                 if (!(lt == RTG_BLOCK || lt == RTG_SPHERE || lt == RTG_XY_RECT || lt == RTG_XZ_RECT || lt == RTG_YZ_RECT))
-                    return fail("ConstantMedium boundary must be a Sphere, or a Block / rectangle / Sphere under Translate / RotateY");
+                    return fail("ConstantMedium boundary must be a Sphere, Block or rectangle, bare or under Translate / RotateY / Transform / FlipFace");
             }
             const uint32_t id = next_id++;
             const size_t first = boundary.size();
+            Wrap outer = w;
+            outer.flip = false;
+            const int outer_xf = xform_index(outer);
             boundary_mode = true;
-            const bool ok = walk(ch[0], Wrap{}, depth + 1);
+            const bool ok = walk(ch[0], outer, depth + 1);
             boundary_mode = false;
             if (!ok) return false;
-            for (size_t k = first; k < boundary.size(); ++k) {
-                int32_t w4, fl = 0;
-                memcpy(&w4, &boundary[k].w[4], 4);
-                if ((w4 >> 8) > 0) memcpy(&fl, &out->xforms[(size_t)((w4 >> 8) - 1) * RT_REC_FLOATS], 4);
-                if (fl & 8) return fail("ConstantMedium boundary under more than one Translate(RotateY(.)) is not supported");
-            }
             float rec[RT_REC_FLOATS] = {i2f((int32_t)first) /* + the number of other slots, added when the slot array is laid out */,
-                                        i2f((int32_t)(boundary.size() - first)), 0.0f, 0.0f, -1.0f / n.f[0], i2f(n.material), i2f((int32_t)id), i2f(1)};
+                                        i2f((int32_t)(boundary.size() - first)), i2f(outer_xf + 1), 0.0f, -1.0f / n.f[0], i2f(n.material), i2f((int32_t)id), i2f(1)};
             out->media.insert(out->media.end(), rec, rec + RT_REC_FLOATS);
             return true;
         }

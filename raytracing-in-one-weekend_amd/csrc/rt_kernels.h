@@ -233,6 +233,20 @@ RT_DEV void record_out_one(const DScene &sc, float4 xa, float4 xb, V3 d_in, V3 &
     }
 }
 
+// ... of a whole record: a chain's wrappers innermost first, each one seeing the ray its own wrappers were given.
+template <int EXT = EXT_ALL>
+RT_DEV void record_out(const DScene &sc, float4 xa, float4 xb, const Ray &r_world, V3 &p, V3 &nn, bool &front) {
+    if ((EXT & EXT_CHAIN) && (f2i(xa.x) & 8)) {
+        const int first = f2i(xa.y), count = f2i(xa.z);
+        for (int k = count - 1; k >= 0; --k) {
+            Ray q = r_world;
+            for (int j = 0; j < k; ++j) q = to_object_one<EXT>(sc, sc.xforms[2 * (first + j)], sc.xforms[2 * (first + j) + 1], q);
+            record_out_one<EXT>(sc, sc.xforms[2 * (first + k)], sc.xforms[2 * (first + k) + 1], q.d, p, nn, front);
+        }
+    } else
+        record_out_one<EXT>(sc, xa, xb, r_world.d, p, nn, front);
+}
+
 // A slot as the kernels read it: all 64 bytes at once, so that the loads of a test do not wait on
 // each other.  In the DEVICE copy of the slot array, spheres and rectangles under a transform carry
 // that transform's record in words 8..15 (unused by those types; written by rt_scene_upload), so
@@ -587,17 +601,7 @@ RT_DEV Rec slot_record(const DScene &sc, uint32_t slot, const Ray &r_world, floa
     }
     bool front = dot(r.d, n) < 0.0f;  // hittable.rs:26
     V3 nn = front ? n : -n;
-    if (xf >= 0) {
-        if ((EXT & EXT_CHAIN) && (f2i(xa.x) & 8)) {   // chain: innermost record first; each one sees the ray its wrappers were given
-            const int first = f2i(xa.y), count = f2i(xa.z);
-            for (int k = count - 1; k >= 0; --k) {
-                Ray q = r_world;
-                for (int j = 0; j < k; ++j) q = to_object_one<EXT>(sc, sc.xforms[2 * (first + j)], sc.xforms[2 * (first + j) + 1], q);
-                record_out_one<EXT>(sc, sc.xforms[2 * (first + k)], sc.xforms[2 * (first + k) + 1], q.d, p, nn, front);
-            }
-        } else
-            record_out_one<EXT>(sc, xa, xb, r_world.d, p, nn, front);
-    }
+    if (xf >= 0) record_out<EXT>(sc, xa, xb, r_world, p, nn, front);
     if (w4 & 16) front = !front;  // flip_face.rs:24-27
     rec.p = p; rec.normal = nn; rec.front_face = front;
     return rec;
@@ -798,13 +802,13 @@ RT_DEV void traverse(const DScene &sc, const Ray &r, float t_min, int32_t floor_
 // boundary.hit() of a medium whose boundary is not a plain sphere: the boundary's leaves are slots [first, first + count)
 // (a Block's six sides, a rectangle, a sphere; under Translate / RotateY) and the hit is HittableList::hit's fold over them,
 // literally: the later candidate replaces the kept one unless kept.t < t (hittable_list.rs:43-49; block.rs:111-113).
-template <bool STATS>
+template <bool STATS, int EXT>
 RT_DEV bool boundary_hit(const DScene &sc, uint32_t first, uint32_t count, const Ray &r, float t_min, float t_max, float *t_out, Counters &cnt) {
     bool have = false;
     float kept = 0.0f;
     for (uint32_t i = 0; i < count; ++i) {
         float t; int32_t id;
-        if (!slot_hit<STATS, EXT_NONE>(sc, first + i, r, t_min, t_max, &t, &id, cnt)) continue;
+        if (!slot_hit<STATS, EXT & (EXT_XFORM | EXT_CHAIN)>(sc, first + i, r, t_min, t_max, &t, &id, cnt)) continue;
         if (!have || !(kept < t)) kept = t;
         have = true;
     }
@@ -812,16 +816,20 @@ RT_DEV bool boundary_hit(const DScene &sc, uint32_t first, uint32_t count, const
     return have;
 }
 
-template <bool STATS>
-RT_DEV bool medium_hit(const DScene &sc, uint32_t m, const Ray &r, float t_min, float t_max, rts::Rng &rng, float *t_out, Counters &cnt) {
+template <bool STATS, int EXT>
+RT_DEV bool medium_hit(const DScene &sc, uint32_t m, const Ray &r_world, float t_min, float t_max, rts::Rng &rng, float *t_out, Counters &cnt) {
     float4 a = sc.media[2 * m], b = sc.media[2 * m + 1];
     if (STATS) cnt.medium_tests += 1;
     V3 c = v3(a.x, a.y, a.z);
     float t1, t2;
+    Ray r = r_world;
     if (f2i(b.w) == 1) {     // general boundary (rt_api.h medium record)
         const uint32_t first = (uint32_t)f2i(a.x), count = (uint32_t)f2i(a.y);
-        if (!boundary_hit<STATS>(sc, first, count, r, -RT_F32_MAX, RT_F32_MAX, &t1, cnt)) return false;
-        if (!boundary_hit<STATS>(sc, first, count, r, t1 + 0.0001f, RT_F32_MAX, &t2, cnt)) return false;
+        // (the boundary slots carry the medium's own wrappers too, so they take the ray as it is)
+        if (!boundary_hit<STATS, EXT>(sc, first, count, r_world, -RT_F32_MAX, RT_F32_MAX, &t1, cnt)) return false;
+        if (!boundary_hit<STATS, EXT>(sc, first, count, r_world, t1 + 0.0001f, RT_F32_MAX, &t2, cnt)) return false;
+        const int outer = f2i(a.z) - 1;          // the medium's own wrappers: the ray's length is measured in their frame
+        if (outer >= 0) r = to_object<EXT>(sc, outer, r_world);
     } else {
     if (!sphere_roots(c, a.w, r, -RT_F32_MAX, RT_F32_MAX, &t1)) return false;
     if (!sphere_roots(c, a.w, r, t1 + 0.0001f, RT_F32_MAX, &t2)) return false;
@@ -928,7 +936,7 @@ RT_DEV bool closest_hit(const DScene &sc, const Ray &r, float t_min, float t_max
 #pragma unroll
     for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m) {
         med_ok[m] = false; med_t[m] = 0.0f;
-        if ((EXT & EXT_MEDIA) && with_media && m < sc.n_media) med_ok[m] = medium_hit<STATS>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
+        if ((EXT & EXT_MEDIA) && with_media && m < sc.n_media) med_ok[m] = medium_hit<STATS, EXT>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
     }
     if (!ray_is_finite(r)) {
         closest_hit_exhaustive<STATS, EXT>(sc, r, t_min, t_max, med_t, med_ok, best, cnt);
@@ -991,7 +999,7 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
 #pragma unroll
     for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m) {
         med_ok[m] = false; med_t[m] = 0.0f;
-        if ((EXT & EXT_MEDIA) && m < sc.n_media) med_ok[m] = medium_hit<STATS>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
+        if ((EXT & EXT_MEDIA) && m < sc.n_media) med_ok[m] = medium_hit<STATS, EXT>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
     }
     RG_END(RG_B_MEDIA);
     tv.floor_id = -1; tv.sp = 0; tv.ref = RT_BVH_EMPTY;
@@ -1441,6 +1449,12 @@ RT_DEV bool shade_record(const DScene &sc, Path &ps, const Hit &best, V3 backgro
         rec.p = ps.ray.at(best.t);
         rec.normal = v3(1.0f, 0.0f, 0.0f);
         rec.front_face = true;
+        const int outer = f2i(mb.w) == 1 ? f2i(sc.media[2 * m].z) - 1 : -1;
+        if (outer >= 0) {      // a medium under wrappers of its own: the point is made in their frame and taken out through them
+            const float4 xa = sc.xforms[2 * outer], xb = sc.xforms[2 * outer + 1];
+            rec.p = to_object_rec<EXT>(sc, xa, xb, ps.ray).at(best.t);
+            record_out<EXT>(sc, xa, xb, ps.ray, rec.p, rec.normal, rec.front_face);
+        }
         rec.material = f2i(mb.y);
         rec.u = 0.0f; rec.v = 0.0f;
         int tex = f2i(sc.materials[2 * rec.material].y);

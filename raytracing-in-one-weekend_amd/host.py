@@ -238,6 +238,9 @@ class FlatScene:
     def xforms(self):
         return np.ctypeslib.as_array(self.desc.xforms, (self.desc.n_xforms, 8)).copy() if self.desc.n_xforms else np.zeros((0, 8), np.float32)
 
+    def media(self):
+        return np.ctypeslib.as_array(self.desc.media, (self.desc.n_media, 8)).copy() if self.desc.n_media else np.zeros((0, 8), np.float32)
+
     def nodes(self):
         return np.ctypeslib.as_array(self.desc.bvh_nodes, (self.desc.n_bvh_nodes, 16)).copy() if self.desc.n_bvh_nodes else np.zeros((0, 16), np.float32)
 

@@ -625,3 +625,45 @@ def test_checkers_of_every_shape(rt, gpu):
     assert np.isfinite(g_img).all()
     ev = stats["tex_evals"]
     assert ev[1] > ev[0] * 0.5 and ev[2] > 0 and ev[3] > 0      # checkers (several levels per hit), noise and image branches were all taken
+
+
+def wrapped_media_scene(rt):
+    """constant_medium.rs:13-39 takes any boundary and is itself a Hittable that any wrapper takes: media under wrappers of their
+    own, over boundaries under Transforms and under more than one record, in a lit room."""
+    s = rt.host.Scene()
+    white = s.lambertian(s.solid(0.73, 0.73, 0.73))
+    red = s.lambertian(s.solid(0.65, 0.05, 0.05))
+    green = s.lambertian(s.solid(0.12, 0.45, 0.15))
+    lamp = s.diffuse_light(s.solid(7, 7, 7))
+    light = s.xz_rect(113, 443, 127, 432, 554, lamp)
+    objs = [s.yz_rect(0, 555, 0, 555, 555, green), s.yz_rect(0, 555, 0, 555, 0, red), s.flip_face(light),
+            s.xz_rect(0, 555, 0, 555, 0, white), s.xz_rect(0, 555, 0, 555, 555, white), s.xy_rect(0, 555, 0, 555, 555, white)]
+    block = lambda: s.block((0, 0, 0), (165, 165, 165), white)
+    # a medium under RotateY(Translate(.)) over a bare block: T and R are the MEDIUM's wrappers
+    objs.append(s.rotate_y(s.translate(s.constant_medium(block(), s.solid(0.1, 0.1, 0.1), 0.012), (60, 0, 330)), 12.0))
+    # ... under a Translate, over a boundary that has a RotateY of its own and a Translate above that (two records)
+    objs.append(s.translate(s.constant_medium(s.translate(s.rotate_y(block(), -20.0), (0, 10, 0)), s.solid(0.9, 0.9, 0.9), 0.015), (300, 0, 60)))
+    # ... under a general Transform (a sheared sphere of smoke), and a plain medium over a block under a general Transform
+    shear = np.eye(4, dtype=np.float32); shear[0, 1] = 0.35; shear[1, 1] = 1.3; shear[:3, 3] = (130, 260, 150)
+    objs.append(s.transform(s.constant_medium(s.sphere((0, 0, 0), 70, white), s.solid(0.2, 0.4, 0.9), 0.02), shear))
+    squash = np.diag([1.2, 0.5, 1.0, 1.0]).astype(np.float32); squash[:3, 3] = (330, 300, 300)
+    objs.append(s.constant_medium(s.transform(s.rotate_y(block(), 30.0), squash), s.solid(0.9, 0.6, 0.2), 0.01))
+    s.set_roots(s.hittable_list(objs), s.hittable_list([light]))
+    params = rt.host.RaytracerConfig.load().scene_params("CornellBox").replace(image_width=96, samples_per_pixel=16)
+    return s, params
+
+
+def test_media_under_wrappers_and_over_wrapped_boundaries(rt, gpu):
+    """Where a medium's hit is made — in the frame of the medium's own wrappers (the ray's length, the hit point and its way out,
+    constant_medium.rs:76-93 inside transform.rs' hit()s) — decides the bits of everything a path does afterwards: per-pixel ray
+    counts against the oracle's nested objects, images to the bar of DESIGN.md section 5."""
+    s, params = wrapped_media_scene(rt)
+    flat = s.flatten()
+    med = flat.media().view(np.int32)
+    assert med.shape[0] == 4 and (med[:, 7] == 1).all() and (med[:3, 2] > 0).all() and med[3, 2] == 0
+    camera = params.camera()
+    sampler = rt.host.MultiJitteredSampler(16)
+    gpu.upload_scene(flat)
+    gpu.upload_sampler(sampler)
+    _, _, st = compare_images(rt, gpu, O.OracleScene(s), params, camera, sampler)
+    assert st["medium_tests"] > 0 and st["shades"][4] > 1000          # isotropic scatters happened

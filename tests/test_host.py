@@ -338,7 +338,18 @@ def test_any_wrapper_nesting_flattens_to_chain_records(rt):
         s.transform(s.sphere((0, 0, 0), 1, m), np.diag([1.0, 0.0, 1.0, 1.0]))
     smoke = s.constant_medium(s.translate(s.translate(s.block((0, 0, 0), (1, 1, 1), m), (1, 0, 0)), (1, 0, 0)), s.solid(1, 1, 1), 0.1)
     s.set_roots(s.hittable_list([smoke]), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
-    with pytest.raises(rt.RtError):                                # a medium's boundary takes one Translate(RotateY(.)) only
+    f2 = s.flatten()                                               # a boundary under two Translates: six boundary slots under a chain
+    med = f2.media()
+    assert med.shape[0] == 1 and med[0].view(np.int32)[7] == 1 and med[0].view(np.int32)[1] == 6 and med[0].view(np.int32)[2] == 0
+    wrapped = s.rotate_y(s.constant_medium(s.translate(s.sphere((0, 1, 0), 1, m), (2, 0, 0)), s.solid(1, 1, 1), 0.2), 30.0)
+    s.set_roots(s.hittable_list([wrapped]), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
+    f3 = s.flatten()                                               # a medium under a wrapper of its own: its record names that wrapper
+    med, x = f3.media(), f3.xforms()
+    outer = med[0].view(np.int32)[2] - 1
+    assert med[0].view(np.int32)[7] == 1 and med[0].view(np.int32)[1] == 1 and outer >= 0 and x[outer].view(np.int32)[0] == 1   # RotateY alone
+    quad = s.constant_medium(s.cylinder(1, -1, 1, 6.0, m), s.solid(1, 1, 1), 0.2)
+    s.set_roots(s.hittable_list([quad]), s.hittable_list([s.sphere((0, 9, 0), 1, m)]))
+    with pytest.raises(rt.RtError):                                # a quadric (or a mesh, a list, another medium) as the boundary
         s.flatten()
 
 
