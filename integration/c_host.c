@@ -26,7 +26,8 @@ _Static_assert(offsetof(rt_render_params, pixel_rays) == 184 && offsetof(rt_rend
 _Static_assert(sizeof(rt_render_params) == 208, "rt_render_params");
 _Static_assert(sizeof(rt_sampler_desc) == 32, "rt_sampler_desc");
 _Static_assert(offsetof(rt_scene_desc, slots) == 32 && offsetof(rt_scene_desc, texels) == 160 && offsetof(rt_scene_desc, matrices) == 208, "rt_scene_desc");
-_Static_assert(sizeof(rt_scene_desc) == 240 && sizeof(rt_scene_info) == 28 && sizeof(rt_stats) == 288 && sizeof(rth_user_config) == 100, "sizes");
+_Static_assert(offsetof(rt_scene_desc, far_limit) == 240 && offsetof(rt_scene_desc, bvh_leaf_max) == 236, "rt_scene_desc tail");
+_Static_assert(sizeof(rt_scene_desc) == 248 && sizeof(rt_scene_info) == 28 && sizeof(rt_stats) == 288 && sizeof(rth_user_config) == 100, "sizes");
 
 #define CHECK(call)                                                                                     \
     do {                                                                                                \

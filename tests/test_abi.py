@@ -60,3 +60,14 @@ def test_no_gpu_means_a_loud_error_not_a_fallback(rt):
     assert e.value.status == -6
     src = open(os.path.join(ROOT, "raytracing-in-one-weekend_amd", "backend.py")).read()
     assert "oracle" not in src.replace("CPU oracle", "")
+
+
+def test_the_c_host_compiles_against_the_headers_as_they_are():
+    """integration/c_host.c carries _Static_asserts on every struct's size and field offsets (what integration/gpu_ffi.rs mirrors):
+    a header change that forgets them — or a c_host binary left over from before it — must not go unnoticed.  Syntax and
+    assertions only (no link: the libraries are not needed for this)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "integration", "c_host.c")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
