@@ -275,6 +275,7 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     ctx->wf_last = n_frames == 1 ? 0 : (ctx->wf_last + 1) % n_frames;
     WfSpace &S = ctx->wf[ctx->wf_last];
     { const int rc = settle(ctx, S); if (rc != RT_OK) return rc; }
+    for (int &f : S.final_at) f = -1;     // (a call that failed or was cancelled half-way may have left some set)
     if (S.samples_entries < need_samples) {
         if (S.samples) { (void)hipDeviceSynchronize(); (void)hipFree(S.samples); S.samples = nullptr; S.samples_entries = 0; }
         HIP_TRY(ctx, hipMalloc((void **)&S.samples, need_samples * 16));

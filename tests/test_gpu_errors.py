@@ -351,3 +351,36 @@ def test_tuning_knobs_are_ignored_unless_RT_KNOBS_is_set(rt, ctx):
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+def test_a_cancel_raised_in_mid_render_ends_the_call_and_leaves_the_context_usable(rt, ctx):
+    """main.rs:1338: the workers poll a flag between blocks; rt_render polls `cancel` between groups of iterations.  A render that
+    is cancelled half-way returns RT_E_CANCELLED once the device is idle; the next render gives the bits it always gave."""
+    import os
+    import threading
+    b, flat, params, camera, sampler = ctx
+    b.upload_scene(flat)
+    b.upload_sampler(sampler)
+    want, _ = b.render(params, camera)
+    p, W, H = b._params(params, camera, 0x5EED, 0, None, None, 2048, 2048)
+    p.out_location = rt._ffi.RT_MEM_DEVICE
+    acc = b.device_alloc(W * H * 16)
+    cancel = C.c_int32(0)
+    p.cancel = C.pointer(cancel)
+    # 1.7e7 paths through a pool of 16 Ki entries per pipeline: thousands of iterations, a tenth of a second at least
+    old = {k: os.environ.get(k) for k in ("RT_KNOBS", "RT_WF_POOL_LOG2")}
+    os.environ.update(RT_KNOBS="1", RT_WF_POOL_LOG2="14")
+    try:
+        timer = threading.Timer(0.02, lambda: setattr(cancel, "value", 1))
+        timer.start()
+        st = b._L.rt_render(b._h, C.byref(p), acc, None)          # (ctypes releases the GIL for the call)
+        timer.join()
+        assert st == RT_E_CANCELLED, (st, b._L.rt_last_error(b._h))
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+        b.device_free(acc)
+    got, _ = b.render(params, camera)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
