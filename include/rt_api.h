@@ -270,7 +270,10 @@ int rt_sampler_upload(rt_ctx *ctx, const rt_sampler_desc *sampler);
  * run (rt_stream_create; different output buffers, or the caller orders the calls: the sums are added
  * into out_rgba_sum by the frame's last kernel).  Calls on one stream run one after the other as before.
  * A third call first waits for the first to end; rt_scene_upload, rt_sampler_upload and rt_destroy wait
- * for every frame in flight.  (HIP gives a process 4 hardware queues by default and then lets the streams
+ * for every frame in flight.  The one thing the host no longer sees before it returns is the pipeline's last
+ * status (an empty pool, every item handed out — what the bound on its iterations guarantees): the call
+ * that next waits for that frame (the render after next, an upload, rt_synchronize) checks it and
+ * reports RT_E_HIP if it does not hold.  (HIP gives a process 4 hardware queues by default and then lets the streams
  * of two frames share them, which serialises the frames: set GPU_MAX_HW_QUEUES=8 in the environment.) */
 int rt_render(rt_ctx *ctx, const rt_render_params *params, float *out_rgba_sum, rt_stats *stats);
 
