@@ -268,9 +268,21 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     int n_pipes = (int)env_size("RT_WF_PIPES", many_items && modest_tree ? 3 : 2, 1, kMaxPipes);
     if (need_samples < 4 * shard_q || n_tiles < 2u) n_pipes = 1;
     if ((uint32_t)n_pipes > n_tiles) n_pipes = (int)n_tiles;      // every pipeline gets at least one tile (magic_div(tiles_pipe) divides by it)
-    size_t pool_want = ((size_t)1 << env_size("RT_WF_POOL_LOG2", 23, 14, 26)) / (size_t)n_pipes;   // per pipeline
-    pool_want = pool_want / shard_q * shard_q;
-    if (pool_want < shard_q) pool_want = shard_q;
+    // Pool: 2^23 entries over all pipelines — what fits the caches, and the best size for every call of up to a few hundred
+    // million items and for scenes without a tree at any size (the Cornell box loses 3 ... 13 % with more) — and 2^25 for a call
+    // of 2^28 items or more on a scene with a tree: a launch of the traversal kernel ends with its longest walks, and four times
+    // the rays per launch pay for that four times less often.  Measured (profiles/r3/ab_pool_by_call_size.txt): Book-2 from 500 spp
+    // +3 %, the mesh at 256 spp +4.6 %, Book-1 at 1000 spp -0.3 %; 2^26 and 2^27 are 1 % behind 2^25 again.  (The same file
+    // keeps the numbers that first led here, +20 ... +30 % for Book-2 with 2^27: those were the serial folds of
+    // rt_kernels.h coop_exhaustive, which a larger pool met less often per ray.)
+    const uint64_t call_items = (uint64_t)per_sample * (uint64_t)a.spp_count;
+    size_t pool_log2 = env_size("RT_WF_POOL_LOG2", has_bvh && call_items >= (1ull << 28) ? 25 : 23, 14, 28);
+    size_t pool_want = 0;
+    auto set_pool_want = [&]() {       // per pipeline
+        pool_want = (((size_t)1 << pool_log2) / (size_t)n_pipes) / shard_q * shard_q;
+        if (pool_want < shard_q) pool_want = shard_q;
+    };
+    set_pool_want();
     // workspace: the one the last render did not use, once the frame that used it before has settled.  With two of them a
     // frame's last launches (C1 at 10 spp: 0.6 of its 2.5 ms are the tail kernel on a few hundred waves) run beside the next
     // frame's first ones when the caller orders the two on different streams; RT_WF_FRAMES=1 keeps one workspace, and a render
@@ -288,12 +300,18 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     }
     const size_t per_pipe_items = (need_samples + n_pipes - 1) / n_pipes;
     size_t pool = per_pipe_items < pool_want ? (per_pipe_items + shard_q - 1) / shard_q * shard_q : pool_want;
-    if (S.pool_entries < pool || S.pool_pipes < n_pipes) {   // two buffers of the largest pool seen for each of the most pipelines seen
+    while (S.pool_entries < pool || S.pool_pipes < n_pipes) {   // two buffers of the largest pool seen for each of the most pipelines seen
         const size_t entries = pool > S.pool_entries ? pool : S.pool_entries;
         const int pipes = n_pipes > S.pool_pipes ? n_pipes : S.pool_pipes;
         if (S.pool) { (void)hipDeviceSynchronize(); (void)hipFree(S.pool); S.pool = nullptr; S.pool_entries = 0; S.pool_pipes = 0; }
-        HIP_TRY(ctx, hipMalloc(&S.pool, entries * 2 * kEntryBytes * (size_t)pipes));
-        S.pool_entries = entries; S.pool_pipes = pipes;
+        const hipError_t e = hipMalloc(&S.pool, entries * 2 * kEntryBytes * (size_t)pipes);
+        if (e == hipSuccess) { S.pool_entries = entries; S.pool_pipes = pipes; break; }
+        S.pool = nullptr;
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory || pool_log2 <= 23) return fail(ctx, e == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP, "path pool of %zu entries: %s", entries * 2 * (size_t)pipes, hipGetErrorString(e));
+        pool_log2 -= 2;          // a large pool is a matter of speed only: go on with a smaller one
+        set_pool_want();
+        pool = per_pipe_items < pool_want ? (per_pipe_items + shard_q - 1) / shard_q * shard_q : pool_want;
     }
     // counters, status words, streams and events: made when first needed and kept (what exists after a failure is used by the
     // next call or released by rt_destroy).  (Measured and dropped, profiles/r3/ab_frames_in_flight.txt: a second stream of the

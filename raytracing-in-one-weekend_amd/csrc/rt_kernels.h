@@ -975,6 +975,113 @@ RT_DEV bool closest_hit(const DScene &sc, const Ray &r, float t_min, float t_max
     return any;
 }
 
+/* ------------------------------------------------------------------ the rare serial folds, by the whole wave */
+
+// A ray that is not finite takes the literal fold over every slot, twice (closest_hit_exhaustive), and a finite ray with a
+// direction component of exactly zero looks at every rectangle for a NaN candidate: loops of dependent loads over thousands
+// of slots (Book-2: 3 409 slots, 2 400 of them rectangles — 1.5 ms for one lane) that a launch of the pipeline's kernels cannot
+// end before.  Such rays are rare — Book-2 at 100 spp: one path in 64 million turns NaN, and forty rays come out of
+// random_in_unit_sphere with a zero — but a NaN path stays NaN until its depth runs out, and each of its bounces held a shade
+// launch for those 1.5 ms: 45 of the frame's 80 ms (profiles/r3/ab_coop_folds.txt).  So the wave runs these loops together, one
+// such ray at a time: lane l tests slots l, l + 64, ... of the leader's ray, and the partial results are folded with the serial
+// loop's own rules — which do not depend on the order of the tests: the last NaN candidate is the one with the largest id (the
+// first slot among equals), the closest hit the smallest t, then the largest id, then the first slot.  Same candidates, same
+// comparisons, same winner, same bits.  All lanes of the wave must call these (with `need` false for a lane without such a ray).
+
+RT_DEV Ray wave_ray_of(const Ray &r, bool mine, int leader) {
+    Ray o;     // (a lane without a ray may hold anything in r: it hands on zeros)
+    o.o = v3(__shfl(mine ? r.o.x : 0.0f, leader, 64), __shfl(mine ? r.o.y : 0.0f, leader, 64), __shfl(mine ? r.o.z : 0.0f, leader, 64));
+    o.d = v3(__shfl(mine ? r.d.x : 0.0f, leader, 64), __shfl(mine ? r.d.y : 0.0f, leader, 64), __shfl(mine ? r.d.z : 0.0f, leader, 64));
+    o.time = __shfl(mine ? r.time : 0.0f, leader, 64);
+    return o;
+}
+
+// closest_hit_exhaustive() for the lanes with `need`
+template <bool STATS, int EXT = EXT_ALL>
+RT_DEV void coop_exhaustive(const DScene &sc, bool need, const Ray &r, float t_min, float t_max, const float *med_t, const bool *med_ok,
+                            Hit &best, Counters &cnt) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (unsigned long long todo = __ballot(need); todo != 0ull; todo &= todo - 1ull) {      // wave-uniform
+        const int leader = __builtin_ctzll(todo);
+        const Ray rr = wave_ray_of(r, need, leader);
+        // pass 1: the largest id among the candidates, and the NaN candidate with the largest id
+        int32_t last_id = -1, nan_id = -1, nan_slot = 0x7fffffff;
+        float nan_t = 0.0f;
+        for (uint32_t s = lane; s < sc.n_slots; s += 64u) {
+            float t; int32_t id;
+            if (!slot_hit<STATS, EXT>(sc, s, rr, t_min, t_max, &t, &id, cnt)) continue;
+            if (id > last_id) last_id = id;
+            if (t != t && id > nan_id) { nan_id = id; nan_slot = (int32_t)s; nan_t = t; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int32_t oid = __shfl_xor(last_id, o, 64), nid = __shfl_xor(nan_id, o, 64), ns = __shfl_xor(nan_slot, o, 64);
+            const float nt = __shfl_xor(nan_t, o, 64);
+            if (oid > last_id) last_id = oid;
+            if (nid > nan_id || (nid == nan_id && ns < nan_slot)) { nan_id = nid; nan_slot = ns; nan_t = nt; }
+        }
+        float lm_t[RT_MAX_MEDIA];
+        bool lm_ok[RT_MAX_MEDIA];
+#pragma unroll
+        for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m) {      // the leader's media candidates, after the slots as in the serial fold
+            lm_ok[m] = (EXT & EXT_MEDIA) && m < sc.n_media && __shfl(need && med_ok[m] ? 1 : 0, leader, 64) != 0;
+            lm_t[m] = __shfl(need ? med_t[m] : 0.0f, leader, 64);
+            if (!lm_ok[m]) continue;
+            const int32_t id = f2i(sc.media[2 * m + 1].z);
+            if (id > last_id) last_id = id;
+            if (lm_t[m] != lm_t[m] && id > nan_id) { nan_id = id; nan_slot = -(int32_t)(m + 1); nan_t = lm_t[m]; }
+        }
+        Hit res;
+        res.t = INFINITY; res.id = -1; res.slot = 0;
+        if (last_id >= 0) {                                // wave-uniform from here on
+            if (nan_id == last_id) { res.t = nan_t; res.id = nan_id; res.slot = nan_slot; }
+            else {
+                // pass 2: the closest of what comes after that NaN candidate (none of those has a NaN distance)
+                bool any = false;
+                float bt = 0.0f;
+                int32_t bid = -1, bslot = 0x7fffffff;
+                for (uint32_t s = lane; s < sc.n_slots; s += 64u) {
+                    float t; int32_t id;
+                    if (!slot_hit<false, EXT>(sc, s, rr, t_min, t_max, &t, &id, cnt)) continue;
+                    if (id <= nan_id) continue;
+                    if (!any || t < bt || (t == bt && id > bid)) { bt = t; bid = id; bslot = (int32_t)s; any = true; }
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const bool oany = __shfl_xor(any ? 1 : 0, o, 64) != 0;
+                    const float ot = __shfl_xor(bt, o, 64);
+                    const int32_t oid = __shfl_xor(bid, o, 64), oslot = __shfl_xor(bslot, o, 64);
+                    if (oany && (!any || ot < bt || (ot == bt && (oid > bid || (oid == bid && oslot < bslot))))) { bt = ot; bid = oid; bslot = oslot; any = true; }
+                }
+#pragma unroll
+                for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m) {
+                    if (!lm_ok[m]) continue;
+                    const int32_t id = f2i(sc.media[2 * m + 1].z);
+                    if (id <= nan_id) continue;
+                    if (!any || lm_t[m] < bt || (lm_t[m] == bt && id > bid)) { bt = lm_t[m]; bid = id; bslot = -(int32_t)(m + 1); any = true; }
+                }
+                if (any) { res.t = bt; res.id = bid; res.slot = bslot; }
+            }
+        }
+        if ((int)lane == leader) best = res;
+    }
+}
+
+// The id of the last NaN candidate among the rectangles (closest_hit's floor_id) for the lanes with `need`
+template <bool STATS, int EXT = EXT_ALL>
+RT_DEV void coop_rect_floor(const DScene &sc, bool need, const Ray &r, float t_min, float t_max, int32_t &floor_id, Counters &cnt) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (unsigned long long todo = __ballot(need); todo != 0ull; todo &= todo - 1ull) {
+        const int leader = __builtin_ctzll(todo);
+        const Ray rr = wave_ray_of(r, need, leader);
+        int32_t f = -1;
+        for (uint32_t i = lane; i < sc.n_rects; i += 64u) {
+            float t; int32_t id;
+            if (slot_hit<STATS, EXT>(sc, sc.rects[i], rr, t_min, t_max, &t, &id, cnt) && t != t && id > f) f = id;
+        }
+        for (int o = 32; o > 0; o >>= 1) { const int32_t of = __shfl_xor(f, o, 64); if (of > f) f = of; }
+        if ((int)lane == leader) floor_id = f;
+    }
+}
+
 /* ------------------------------------------------------------------ resumable traversal (render kernel) */
 
 // The render kernel does not call closest_hit(): it keeps the traversal of every lane in this
@@ -990,31 +1097,19 @@ struct Trav {
     float fat;          // ray_fat(): how much every box is grown for this ray (0: an ordinary ray)
 };
 
-// world.hit() up to the point where the BVH walk starts.  Returns true if there is a walk to do.
-template <bool STATS, int EXT = EXT_ALL>
-RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max, rts::Rng &rng, Trav &tv, Counters &cnt) {
-    float med_t[RT_MAX_MEDIA];
+// What begin_trace() leaves for settle_trace(): the rare serial folds (above), which the wave runs together at a place of the
+// caller's choosing — the end of the kernel, where little else is alive (run where begin_trace is called, their loops over the
+// slots cost every kernel 15 ... 25 VGPRs, and the scenes that never need them 5 ... 10 % of their frame).
+struct LateFolds {
+    bool literal;                 // not a finite ray: the literal fold over every slot (tv.best is still to be found, there is no walk)
+    bool axis;                    // a direction component of exactly zero: a rectangle may hold a NaN candidate (the floor_id)
+    float med_t[RT_MAX_MEDIA];    // the media candidates (they have drawn their random numbers)
     bool med_ok[RT_MAX_MEDIA];
-    RG_BEGIN(RG_B_MEDIA);
-#pragma unroll
-    for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m) {
-        med_ok[m] = false; med_t[m] = 0.0f;
-        if ((EXT & EXT_MEDIA) && m < sc.n_media) med_ok[m] = medium_hit<STATS, EXT>(sc, m, r, t_min, t_max, rng, &med_t[m], cnt);
-    }
-    RG_END(RG_B_MEDIA);
-    tv.floor_id = -1; tv.sp = 0; tv.ref = RT_BVH_EMPTY;
-    RG_BEGIN(RG_B_RECTS);
-    if (!ray_is_finite(r)) {
-        closest_hit_exhaustive<STATS, EXT>(sc, r, t_min, t_max, med_t, med_ok, tv.best, cnt);
-        RG_END(RG_B_RECTS);
-        return false;
-    }
-    if (r.d.x == 0.0f || r.d.y == 0.0f || r.d.z == 0.0f)
-        for (uint32_t i = 0; i < sc.n_rects; ++i) {
-            float t; int32_t id;
-            if (slot_hit<STATS, EXT>(sc, sc.rects[i], r, t_min, t_max, &t, &id, cnt) && t != t && id > tv.floor_id) tv.floor_id = id;
-        }
-    RG_END(RG_B_RECTS);
+};
+
+// world.hit() from the always-list to the start of the BVH walk, for a finite ray whose last NaN candidate is tv.floor_id.
+template <bool STATS, int EXT = EXT_ALL>
+RT_DEV bool begin_trace_rest(const DScene &sc, const Ray &r, float t_min, float t_max, Trav &tv, const float *med_t, const bool *med_ok, Counters &cnt) {
     tv.best.t = t_max; tv.best.id = -1; tv.best.slot = 0;
     RG_BEGIN(RG_B_ALWAYS);
     always_scan<STATS, EXT>(sc, r, t_min, t_max, tv.floor_id, tv.best, cnt);
@@ -1036,6 +1131,50 @@ RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max
     tv.ref = sc.root_ref;
     RG_END(RG_B_REST);
     return true;
+}
+
+// world.hit() up to the point where the BVH walk starts.  Returns true if there is a walk to do.  What `late` names is still
+// owed: every lane of the wave must call settle_trace() afterwards, before anybody looks at tv.
+template <bool STATS, int EXT = EXT_ALL>
+RT_DEV bool begin_trace(const DScene &sc, const Ray &r, float t_min, float t_max, rts::Rng &rng, Trav &tv, Counters &cnt, LateFolds &late) {
+    RG_BEGIN(RG_B_MEDIA);
+#pragma unroll
+    for (uint32_t m = 0; m < RT_MAX_MEDIA; ++m) {
+        late.med_ok[m] = false; late.med_t[m] = 0.0f;
+        if ((EXT & EXT_MEDIA) && m < sc.n_media) late.med_ok[m] = medium_hit<STATS, EXT>(sc, m, r, t_min, t_max, rng, &late.med_t[m], cnt);
+    }
+    RG_END(RG_B_MEDIA);
+    tv.floor_id = -1; tv.sp = 0; tv.ref = RT_BVH_EMPTY;
+    late.literal = !ray_is_finite(r);
+    late.axis = !late.literal && (r.d.x == 0.0f || r.d.y == 0.0f || r.d.z == 0.0f);
+    if (late.literal) { tv.best.t = INFINITY; tv.best.id = -1; tv.best.slot = 0; return false; }
+    return begin_trace_rest<STATS, EXT>(sc, r, t_min, t_max, tv, late.med_t, late.med_ok, cnt);
+}
+
+// The folds begin_trace() left, for the lanes with `active`; called by ALL lanes of the wave.  True for a lane whose tv and
+// `walk` are new (a finite ray's only if a rectangle did hold a NaN candidate: everything after the rectangles is then done
+// again with that floor_id — without counting its tests a second time).
+template <bool STATS, int EXT = EXT_ALL>
+RT_DEV bool settle_trace(const DScene &sc, bool active, const Ray &r, float t_min, float t_max, Trav &tv, bool &walk, const LateFolds &late, Counters &cnt) {
+    const bool literal = active && late.literal, axis = active && late.axis;
+    if (__builtin_expect(__ballot(literal || axis) == 0ull, 1)) return false;
+    RG_BEGIN(RG_B_RECTS);
+    bool changed = false;
+    if (__ballot(literal) != 0ull) {
+        coop_exhaustive<STATS, EXT>(sc, literal, r, t_min, t_max, late.med_t, late.med_ok, tv.best, cnt);
+        changed = literal;
+    }
+    if (__ballot(axis) != 0ull) {
+        int32_t floor_id = -1;
+        coop_rect_floor<STATS, EXT>(sc, axis, r, t_min, t_max, floor_id, cnt);
+        if (axis && floor_id >= 0) {
+            tv.floor_id = floor_id; tv.sp = 0; tv.ref = RT_BVH_EMPTY;
+            walk = begin_trace_rest<false, EXT>(sc, r, t_min, t_max, tv, late.med_t, late.med_ok, cnt);
+            changed = true;
+        }
+    }
+    RG_END(RG_B_RECTS);
+    return changed;
 }
 
 template <bool STATS, bool LT = false>
@@ -1088,14 +1227,30 @@ RT_DEV void hint_sphere(const DScene &sc, uint32_t slot, const Ray &r, float t_m
     if (id > tv.floor_id) consider(tv.best, t, id, (int32_t)slot);
 }
 
-// After the walk: if nothing came after the last NaN candidate, that candidate is the hit.
+// After the walk: if nothing came after the last NaN candidate, that candidate is the hit (the last rectangle, in the order of
+// sc.rects, that answers with its id).  Called by ALL lanes of the wave; the wave looks for one lane's candidate at a time.
 template <bool STATS, int EXT = EXT_ALL>
-RT_DEV void finish_trace(const DScene &sc, const Ray &r, float t_min, float t_max, Trav &tv, Counters &cnt) {
-    if (tv.best.id >= 0 || tv.floor_id < 0) return;
-    for (uint32_t i = 0; i < sc.n_rects; ++i) {
-        float t; int32_t id;
-        uint32_t s = sc.rects[i];
-        if (slot_hit<false, EXT>(sc, s, r, t_min, t_max, &t, &id, cnt) && id == tv.floor_id) { tv.best.t = t; tv.best.id = id; tv.best.slot = (int32_t)s; }
+RT_DEV void finish_trace(const DScene &sc, bool active, const Ray &r, float t_min, float t_max, Trav &tv, Counters &cnt) {
+    const bool need = active && !(tv.best.id >= 0 || tv.floor_id < 0);
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long todo = __ballot(need);
+    if (__builtin_expect(todo == 0ull, 1)) return;
+    for (; todo != 0ull; todo &= todo - 1ull) {
+        const int leader = __builtin_ctzll(todo);
+        const Ray rr = wave_ray_of(r, need, leader);
+        const int32_t want = __shfl(need ? tv.floor_id : -1, leader, 64);
+        int32_t at = -1;
+        float at_t = 0.0f;
+        for (uint32_t i = lane; i < sc.n_rects; i += 64u) {
+            float t; int32_t id;
+            if (slot_hit<false, EXT>(sc, sc.rects[i], rr, t_min, t_max, &t, &id, cnt) && id == want) { at = (int32_t)i; at_t = t; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int32_t oat = __shfl_xor(at, o, 64);
+            const float ot = __shfl_xor(at_t, o, 64);
+            if (oat > at) { at = oat; at_t = ot; }
+        }
+        if ((int)lane == leader && at >= 0) { tv.best.t = at_t; tv.best.id = want; tv.best.slot = (int32_t)sc.rects[at]; }
     }
 }
 

@@ -109,6 +109,13 @@ RT_DEV void store_entry(const PathQ &q, uint32_t i, const WfPath &p, const Trav 
     q.hit[i] = make_float4(tv.best.t, __int_as_float(tv.best.id), __int_as_float(tv.best.slot), __int_as_float(tv.floor_id));
 }
 
+// The words of entry i that settle_trace() may change after store_entry() (same lane, same addresses: in program order).
+RT_DEV void restore_trace(const PathQ &q, uint32_t i, int depth, const Trav &tv, bool walk) {
+    const uint32_t flags = ((uint32_t)depth & WF_DEPTH_MASK) | WF_ALIVE | (walk ? WF_WALK : 0u);
+    reinterpret_cast<float *>(&q.ray_d[i])[3] = __uint_as_float(flags);
+    q.hit[i] = make_float4(tv.best.t, __int_as_float(tv.best.id), __int_as_float(tv.best.slot), __int_as_float(tv.floor_id));
+}
+
 // Append the lanes with `keep` to q at positions taken from *counter (one atomic per wave).
 RT_DEV uint32_t wave_append(uint32_t *counter, bool keep) {
     const unsigned long long m = __ballot(keep);
@@ -186,11 +193,18 @@ RT_DEV void flush_counters(const Counters &cnt, uint32_t paths, unsigned long lo
 // Fills every shard of the next pool buffer behind shade's survivors with new paths and publishes the
 // next iteration's counters.  Thread j looks at pool entry j: items are numbered through the free
 // entries in pool order, so nothing needs an atomic.
+#ifndef RT_WF_SHADE_WAVES
+#define RT_WF_SHADE_WAVES 1     // (1: shade_min_waves' choice)
+#endif
 #ifndef RT_WF_GEN_WAVES
 #define RT_WF_GEN_WAVES 1       // min waves per SIMD the generate kernel is compiled for (1 = the compiler's choice: 112 VGPRs, 4 waves)
 #endif
+// (the register budgets the kernels had before the rare folds of settle_trace() were given to the whole wave: what those loops
+// need beyond it is spilled around them, where it costs nothing)
+constexpr int gen_min_waves(bool stats, int ext) { return stats ? 1 : RT_WF_GEN_WAVES > 1 ? RT_WF_GEN_WAVES : (ext & (EXT_QUADRICS | EXT_CHAIN)) ? 4 : (ext & EXT_TRI) ? 6 : 7; }
+constexpr int shade_min_waves(bool stats, int ext) { return stats ? 1 : RT_WF_SHADE_WAVES > 1 ? RT_WF_SHADE_WAVES : (ext & (EXT_MEDIA | EXT_NOISE | EXT_QUADRICS | EXT_CHAIN)) ? 5 : 7; }
 template <bool STATS, int EXT>
-__global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScene sc, WfArgs w, PathQ nxt, WfCounters *ctr, uint32_t it,
+__global__ void __launch_bounds__(256, gen_min_waves(STATS, EXT)) wf_generate_kernel(DScene sc, WfArgs w, PathQ nxt, WfCounters *ctr, uint32_t it,
                                                           float4 *__restrict__ samples, uint32_t *status, unsigned long long *stats,
                                                           uint32_t *pixel_rays) {
     const WfCounters *c = ctr + (it % RT_WF_RING);
@@ -279,9 +293,15 @@ __global__ void __launch_bounds__(256, RT_WF_GEN_WAVES) wf_generate_kernel(DScen
         p.ps.radiance = v3(0.0f, 0.0f, 0.0f);
         p.ps.depth = w.a.max_depth;
         if (STATS) { cnt.rays += 1; if (pixel_rays) atomicAdd(&pixel_rays[p.pixel], 1u); }
-        const bool walk = begin_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt);
+    }
+    LateFolds late;
+    late.literal = false; late.axis = false;
+    bool walk = false;
+    if (have_ray) {
+        walk = begin_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt, late);
         store_entry(nxt, e, p, tv, walk);
     }
+    if (settle_trace<STATS, EXT>(sc, have_ray, p.ps.ray, 0.001f, INFINITY, tv, walk, late, cnt)) restore_trace(nxt, e, w.a.max_depth, tv, walk);   // (all lanes)
     if (STATS || kTimers) flush_counters<STATS>(cnt, inside ? 1u : 0u, stats, RT_K_GENERATE);
 }
 
@@ -432,9 +452,6 @@ __global__ void __launch_bounds__(256, RT_WF_TRAV_WAVES) wf_traverse_kernel(DSce
 
 // One thread per pool entry: finish the hit, run ray_color's body, start the next ray (everything of
 // world.hit() that comes before the BVH walk), append the survivor to the next buffer.
-#ifndef RT_WF_SHADE_WAVES
-#define RT_WF_SHADE_WAVES 1
-#endif
 
 // The bounce of pool entry i (flags = word 3 of its direction quad `d`, 0 for a lane without an entry).  Called by all lanes of
 // the wave (shade_hit shares the wave's noise hits).
@@ -449,11 +466,21 @@ RT_DEV void shade_entry(const DScene &sc, const WfArgs &w, const PathQ &cur, con
     const bool alive = (flags & WF_ALIVE) != 0u;
     phase_count<STATS>(cnt, PH_SHADE, alive);
     bool cont = false;
+    float4 th = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float2 rg = make_float2(0.0f, 0.0f);
     if (alive) {
         RG_BEGIN(RG_LOAD);
-        const float4 o = cur.ray_o[i], th = cur.thr[i], h = cur.hit[i];
-        const float2 rg = cur.rng[i];
+        const float4 o = cur.ray_o[i], h = cur.hit[i];
+        th = cur.thr[i]; rg = cur.rng[i];
         p.ps.ray.o = v3(o.x, o.y, o.z); p.ps.ray.d = v3(d.x, d.y, d.z); p.ps.ray.time = o.w;
+        tv.best.t = h.x; tv.best.id = f2i(h.y); tv.best.slot = f2i(h.z); tv.floor_id = f2i(h.w);
+        RG_END(RG_LOAD);
+    }
+    RG_BEGIN(RG_FINISH);
+    finish_trace<STATS, EXT>(sc, alive, p.ps.ray, 0.001f, INFINITY, tv, cnt);     // (all lanes; rare, and before the path is unpacked)
+    RG_END(RG_FINISH);
+    if (alive) {
+        RG_BEGIN(RG_LOAD);
         p.ps.throughput = v3(th.x, th.y, th.z); p.item = __float_as_uint(th.w);
         p.ps.radiance = v3(0.0f, 0.0f, 0.0f);
         p.ps.depth = (int)(flags & WF_DEPTH_MASK);
@@ -462,11 +489,7 @@ RT_DEV void shade_entry(const DScene &sc, const WfArgs &w, const PathQ &cur, con
         p.pixel = (uint32_t)py * (uint32_t)w.a.width + (uint32_t)px;
         p.rng.state = ((uint64_t)__float_as_uint(rg.y) << 32) | (uint64_t)__float_as_uint(rg.x);
         p.rng.inc = (((((uint64_t)p.pixel << 24) ^ (uint64_t)p.sample)) << 1u) | 1u;   // rts::path_rng's stream
-        tv.best.t = h.x; tv.best.id = f2i(h.y); tv.best.slot = f2i(h.z); tv.floor_id = f2i(h.w);
         RG_END(RG_LOAD);
-        RG_BEGIN(RG_FINISH);
-        finish_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, tv, cnt);
-        RG_END(RG_FINISH);
     }
     RG_BEGIN(RG_SHADE_ALL);
     cont = shade_hit<STATS, EXT>(sc, alive, p.ps, tv.best, background, p.rng, cnt);     // (all lanes: the wave shares its noise hits)
@@ -479,20 +502,24 @@ RT_DEV void shade_entry(const DScene &sc, const WfArgs &w, const PathQ &cur, con
         }
     }
     phase_count<STATS>(cnt, PH_BEGIN, survive);
+    LateFolds late;
+    late.literal = false; late.axis = false;
     if (survive) {
         if (STATS) { cnt.rays += 1; if (pixel_rays) atomicAdd(&pixel_rays[p.pixel], 1u); }
         RG_BEGIN(RG_BEGIN_ALL);
-        walk = begin_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt);
+        walk = begin_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt, late);
         RG_END(RG_BEGIN_ALL);
     }
     RG_BEGIN(RG_STORE);
     const uint32_t pos = shard * w.cap + wave_append(&ctr_it->sh[shard].n_surv, survive);
     if (survive) store_entry(nxt, pos, p, tv, walk);
     RG_END(RG_STORE);
+    // the rare serial folds last (all lanes), when only the ray is still needed
+    if (settle_trace<STATS, EXT>(sc, survive, p.ps.ray, 0.001f, INFINITY, tv, walk, late, cnt)) restore_trace(nxt, pos, p.ps.depth, tv, walk);
 }
 
 template <bool STATS, int EXT>
-__global__ void __launch_bounds__(256, RT_WF_SHADE_WAVES) wf_shade_kernel(DScene sc_in, WfArgs w, PathQ cur, PathQ nxt, WfCounters *ctr, uint32_t it,
+__global__ void __launch_bounds__(256, shade_min_waves(STATS, EXT)) wf_shade_kernel(DScene sc_in, WfArgs w, PathQ cur, PathQ nxt, WfCounters *ctr, uint32_t it,
                                                        float4 *__restrict__ samples, unsigned long long *stats, uint32_t *pixel_rays, uint32_t with_tail) {
     DScene sc = sc_in;
     const uint32_t shard = blockIdx.y, off0 = blockIdx.x * blockDim.x;   // block-uniform; grid as in wf_generate_kernel
@@ -692,7 +719,7 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
             phase_count<STATS>(cnt, PH_SHADE, alive);
             bool survive = false;
             RG_BEGIN(RG_SHADE_ALL);
-            if (alive) finish_trace<STATS, EXT>(sc, p.ps.ray, T_MIN, INFINITY, tv, cnt);
+            finish_trace<STATS, EXT>(sc, alive, p.ps.ray, T_MIN, INFINITY, tv, cnt);
             if (alive && tv.best.id >= 0) where = (uint32_t)tv.best.slot;
             const bool cont = shade_hit<STATS, EXT>(sc, alive, p.ps, tv.best, background, p.rng, cnt);
             if (alive) {
@@ -706,10 +733,13 @@ __global__ void __launch_bounds__(256) wf_tail_kernel(DScene sc, WfArgs w, PathQ
             RG_END(RG_SHADE_ALL);
             phase_count<STATS>(cnt, PH_BEGIN, survive);
             RG_BEGIN(RG_BEGIN_ALL);
+            LateFolds late;
+            late.literal = false; late.axis = false;
             if (survive) {
                 if (STATS) { cnt.rays += 1; if (pixel_rays) atomicAdd(&pixel_rays[p.pixel], 1u); }
-                walk = begin_trace<STATS, EXT>(sc, p.ps.ray, T_MIN, INFINITY, p.rng, tv, cnt);
+                walk = begin_trace<STATS, EXT>(sc, p.ps.ray, T_MIN, INFINITY, p.rng, tv, cnt, late);
             }
+            settle_trace<STATS, EXT>(sc, survive, p.ps.ray, T_MIN, INFINITY, tv, walk, late, cnt);   // (all lanes)
             RG_END(RG_BEGIN_ALL);
         }
         // What is still alive goes on in the next iteration.  Regrouped: appended to the shard its last hit's slot names, so that the

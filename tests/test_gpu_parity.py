@@ -477,6 +477,45 @@ def test_wrapped_lights_forward_their_pdf_untransformed(rt, gpu):
 
 
 @pytest.mark.gpu
+def test_the_rare_folds_run_by_the_wave_give_the_list_fold(rt, gpu):
+    """Rays that are not finite take the literal fold over every slot, rays with a zero direction component look at every
+    rectangle for a NaN candidate (hittable_list.rs:40-57 with rectangles.rs:25-32 and sphere.rs:61-65 accepting NaN); the wave
+    runs those loops together (rt_kernels.h coop_exhaustive, coop_rect_floor, finish_trace).  A scene of several hundred slots in
+    which such rays are common: a FlipFace entry in `lights` makes every second lambertian bounce aim along (1, 0, 0), which lies
+    in the floor's plane — a NaN distance, a NaN hit point, and from there a path of NaN rays — and a medium hands on rays with a
+    time outside the shutter.  Image, ray total and per-pixel ray counts against the oracle.  (The clutter is a plain list: NaN
+    candidates inside a reference BvhNode are folded in that node's random leaf order)"""
+    s = rt.host.Scene()
+    rng = np.random.default_rng(11)
+    grey, red = s.lambertian(s.solid(0.7, 0.7, 0.7)), s.lambertian(s.solid(0.7, 0.2, 0.2))
+    lamp, dark, glass = s.diffuse_light(s.solid(9, 9, 9)), s.diffuse_light(s.solid(0, 0, 0)), s.dielectric(1.5)
+    clutter = []
+    for k in range(150):
+        c = (float(rng.uniform(-6, 6)), float(rng.uniform(0.2, 3)), float(rng.uniform(-6, 3)))
+        clutter.append(s.sphere(c, float(rng.uniform(0.1, 0.3)), red if k % 3 else glass))
+    for k in range(30):     # 180 rectangles.  They absorb, and none lies in the floor's plane: a ray along (1, 0, 0) that starts ON a
+        # Block's face meets a NaN candidate inside the Block's own list of sides, which the kernels fold flat (DESIGN.md §3)
+        x, z = float(rng.uniform(-6, 5)), float(rng.uniform(-6, 2))
+        clutter.append(s.block((x, 0.25 if k % 2 else 0.5, z), (x + 0.4, 0.9, z + 0.4), dark))
+    fog = s.constant_medium(s.sphere((0, 1, 0), 2.5, glass), s.solid(0.8, 0.8, 0.9), 0.3)
+    world = [s.xz_rect(-20, 20, -20, 20, 0, grey), s.xz_rect(-1, 1, -1, 1, 5, lamp), fog, s.moving_sphere((2, 1, 1), (2, 1.5, 1), 0, 1, 0.4, red)]
+    world += clutter
+    lights = [s.xz_rect(-1, 1, -1, 1, 5, dark), s.flip_face(s.xz_rect(-1, 1, -1, 1, 5, dark))]     # the second: pdf 0, random = (1, 0, 0)
+    s.set_roots(s.hittable_list(world), s.hittable_list(lights))
+    params = rt.host.RaytracerConfig.load().scene_params("CornellBox").replace(
+        image_width=96, aspect_ratio=1.5, samples_per_pixel=16, look_from=(0.0, 3.0, 11.0), look_at=(0.5, 1.5, 0.0),
+        vertical_fov=40.0, background=(0.02, 0.02, 0.03))
+    camera, sampler = params.camera(), rt.host.MultiJitteredSampler(16)
+    flat = s.flatten()
+    assert flat.desc.n_slots > 330 and flat.desc.n_rect_slots > 180 and flat.desc.n_media == 1
+    gpu.upload_scene(flat)
+    gpu.upload_sampler(sampler)
+    g_img, c_img, _ = compare_images(rt, gpu, O.OracleScene(s), params, camera, sampler)
+    nan = np.isnan(g_img[..., :3]).any(-1)
+    assert np.array_equal(nan, np.isnan(c_img[..., :3]).any(-1)) and 0.02 < nan.mean() < 0.98, nan.mean()
+
+
+@pytest.mark.gpu
 def test_moving_sphere_in_lights(rt, gpu):
     """MovingSphere::pdf_value tests the ray against the sphere at time 0 and ::random aims at center(time1) - center(time0), the
     difference of the two centres (objects/sphere.rs:204-226, sic).  Against the oracle, ray counts equal; time0 != 0 so that
