@@ -264,8 +264,10 @@ int rt_sampler_upload(rt_ctx *ctx, const rt_sampler_desc *sampler);
  * the frame's last kernels are queued — the host feeds the pipeline, so for the host it lasts nearly as
  * long as the render, less the frame's last launches (the few paths still alive then: a fifth of a
  * 10-spp frame of Book-1).  `cancel` is polled between groups of eight iterations.
- * FRAMES IN FLIGHT: the context keeps two workspaces in device memory (each: path pool 1.2 GB, sample
- * buffer up to RT_WF_SAMPLES_MB = 8192 MB; grown on demand, kept until rt_destroy) and uses them in turn,
+ * FRAMES IN FLIGHT: the context keeps two workspaces in device memory (each: path pool 1.2 GB — 4.8 GB
+ * once a call of 2^28 items or more was made on a scene with a tree; a pool the device cannot give is
+ * tried again at a quarter of the size —, sample buffer up to RT_WF_SAMPLES_MB = 8192 MB; grown on demand,
+ * kept until rt_destroy) and uses them in turn,
  * so a call ordered on ANOTHER stream than the one before starts while that one's last launches still
  * run (rt_stream_create; different output buffers, or the caller orders the calls: the sums are added
  * into out_rgba_sum by the frame's last kernel).  Calls on one stream run one after the other as before.
