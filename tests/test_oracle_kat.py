@@ -129,6 +129,48 @@ def test_list_tie_later_object_wins():
     assert pid[0] == 1 and t[0] == 1.0
 
 
+def test_list_fold_keeps_what_comes_after_the_last_nan_candidate():
+    """hittable_list.rs:40-50 is `min_by` with a comparator that says Less only if a.t < b.t: the held candidate is replaced unless
+    its t is smaller — so a NaN candidate (a rectangle whose plane contains the ray: (k - o.z) / d.z = 0 / 0, and every range test
+    of rectangles.rs:25-32 is false for NaN) replaces whatever was held, and is itself replaced by whatever comes next.  By hand,
+    for the ray (0.5, 0.5, 0) + t (1, 0, 0): A = xy_rect in z = 0 (NaN), B = sphere at (3, 0.5, 0) r 0.5 (t = 2), C = yz_rect at
+    x = 9 (t = 8.5)."""
+    objs = {"A": lambda s, m: s.xy_rect(0, 1, 0, 1, 0, m), "B": lambda s, m: s.sphere((3, 0.5, 0), 0.5, m), "C": lambda s, m: s.yz_rect(-5, 5, -5, 5, 9, m)}
+    want = {"ABC": ("B", 2.0),      # A; B replaces the NaN; C: 2 < 8.5, B stays
+            "BCA": ("A", None),     # B; C: B stays; A: 2 < NaN is false -> A, with its NaN distance
+            "CAB": ("B", 2.0),      # C; A replaces; B replaces
+            "BAC": ("C", 8.5),      # B; A replaces; C replaces the NaN: the closer B is forgotten
+            "ACB": ("B", 2.0),      # A; C replaces; B: 8.5 < 2 is false -> B
+            "CBA": ("A", None)}
+    for order, (winner, t_want) in want.items():
+        sc = scene_with(lambda s, m: [objs[k](s, m) for k in order])
+        pid, t, *_ = O.OracleScene(sc).first_hit(ray((0.5, 0.5, 0), (1, 0, 0)))
+        assert pid[0] == order.index(winner), (order, pid[0])
+        assert (np.isnan(t[0]) if t_want is None else t[0] == t_want), (order, t[0])
+
+
+def test_a_block_folds_its_sides_before_the_list_sees_it():
+    """block.rs:111-113: a Block's hit() is its own list's hit(), so the enclosing list sees ONE candidate.  The ray
+    (-2, 1, 0.5) + t (1, 0, 0) runs along the top face (y = 1) of the block [2, 3] x [0, 1] x [0, 1]: sides in the order of
+    block.rs:27-79 — XY@z1 and XY@z0 miss (-inf), XZ@y1 is 0 / 0 = NaN, XZ@y0 misses (-inf), YZ@x1 t = 5 replaces the NaN, YZ@x0
+    t = 4 replaces that (5 < 4 is false): the Block answers t = 4.  The sphere at (0, 1, 0.5) r 0.5 is hit at t = 1.5 (half_b = -2,
+    c = 3.75, root = 2 - sqrt(0.25)): in either order the list keeps the sphere.  (Folding the six sides into the enclosing list
+    would let the NaN side wipe out the sphere: Block side at t = 4 — what the GPU kernels do)  Off to the side
+    (z = 5: no YZ side is hit, but the NaN side ignores its extents) the Block answers with the NaN side itself, and the list,
+    which holds the sphere at t = 1.5, takes it: 1.5 < NaN is false."""
+    for order in ("SB", "BS"):
+        build = lambda s, m: [s.sphere((0, 1, 0.5), 0.5, m) if k == "S" else s.block((2, 0, 0), (3, 1, 1), m) for k in order]
+        pid, t, *_ = O.OracleScene(scene_with(build)).first_hit(ray((-2, 1, 0.5), (1, 0, 0)))
+        sphere_id = 0 if order == "SB" else 6          # a Block's sides carry six consecutive ids
+        assert pid[0] == sphere_id and t[0] == 1.5, (order, pid[0], t[0])
+    build = lambda s, m: [s.sphere((0, 1, 5), 0.5, m), s.block((2, 0, 0), (3, 1, 1), m)]
+    pid, t, *_ = O.OracleScene(scene_with(build)).first_hit(ray((-2, 1, 5), (1, 0, 0)))
+    assert pid[0] == 3 and np.isnan(t[0]), (pid[0], t[0])        # sphere 0; XY@z1 1, XY@z0 2, XZ@y1 3
+    build = lambda s, m: [s.block((2, 0, 0), (3, 1, 1), m), s.sphere((0, 1, 5), 0.5, m)]
+    pid, t, *_ = O.OracleScene(scene_with(build)).first_hit(ray((-2, 1, 5), (1, 0, 0)))
+    assert pid[0] == 6 and t[0] == 1.5, (pid[0], t[0])           # the sphere comes after the NaN and replaces it
+
+
 def test_bvh_tie_right_child_wins():
     """bvh.rs:83: `if a.t < b.t {a} else {b}` -> right."""
     s = scene_with(lambda s, m: [s.bvh([s.xy_rect(0, 1, 0, 1, 0, m), s.xy_rect(0, 1, 0, 1, 0, m)])])
