@@ -492,6 +492,11 @@ RT_DEV void shade_entry(const DScene &sc, const WfArgs &w, const PathQ &cur, con
         RG_END(RG_LOAD);
     }
     RG_BEGIN(RG_SHADE_ALL);
+#ifdef RT_DEBUG_PATH
+    if (alive && p.pixel == RT_DEBUG_PIXEL && p.sample == RT_DEBUG_SAMPLE)
+        printf("PATH arrive depth_left %d | ray o %.9g %.9g %.9g d %.9g %.9g %.9g | hit t %.9g (bits %08x) id %d slot %d\n", p.ps.depth, p.ps.ray.o.x, p.ps.ray.o.y, p.ps.ray.o.z,
+               p.ps.ray.d.x, p.ps.ray.d.y, p.ps.ray.d.z, tv.best.t, __float_as_uint(tv.best.t), tv.best.id, tv.best.slot);
+#endif
     cont = shade_hit<STATS, EXT>(sc, alive, p.ps, tv.best, background, p.rng, cnt);     // (all lanes: the wave shares its noise hits)
     RG_END(RG_SHADE_ALL);
     if (alive) {
@@ -510,6 +515,14 @@ RT_DEV void shade_entry(const DScene &sc, const WfArgs &w, const PathQ &cur, con
         walk = begin_trace<STATS, EXT>(sc, p.ps.ray, 0.001f, INFINITY, p.rng, tv, cnt, late);
         RG_END(RG_BEGIN_ALL);
     }
+#ifdef RT_DEBUG_PATH
+    if (alive && p.pixel == RT_DEBUG_PIXEL && p.sample == RT_DEBUG_SAMPLE) {
+        printf("PATH shade depth_left %d survive %d walk %d | new ray o %.9g %.9g %.9g d %.9g %.9g %.9g time %.9g | best t %.9g id %d slot %d | med ok %d %d t %.9g %.9g | o bits %08x %08x %08x d bits %08x %08x %08x time bits %08x\n",
+               p.ps.depth, (int)survive, (int)walk, p.ps.ray.o.x, p.ps.ray.o.y, p.ps.ray.o.z, p.ps.ray.d.x, p.ps.ray.d.y, p.ps.ray.d.z, p.ps.ray.time,
+               tv.best.t, tv.best.id, tv.best.slot, (int)late.med_ok[0], (int)late.med_ok[1], late.med_t[0], late.med_t[1],
+               __float_as_uint(p.ps.ray.o.x), __float_as_uint(p.ps.ray.o.y), __float_as_uint(p.ps.ray.o.z), __float_as_uint(p.ps.ray.d.x), __float_as_uint(p.ps.ray.d.y), __float_as_uint(p.ps.ray.d.z), __float_as_uint(p.ps.ray.time));
+    }
+#endif
     RG_BEGIN(RG_STORE);
     const uint32_t pos = shard * w.cap + wave_append(&ctr_it->sh[shard].n_surv, survive);
     if (survive) store_entry(nxt, pos, p, tv, walk);
