@@ -107,6 +107,14 @@ def test_c1_book1_full_frame(rt, gpu):
     oracle_window(rt, gpu, scene, params, camera, sampler, (560, 300, 688, 396))             # 128x96 window, all 10 spp
 
 
+def test_c1_headline_frame_every_pixel_against_the_oracle(rt, gpu):
+    """BASELINE's headline configuration whole: 1200 x 675 x 10 spp, 21 M rays — ray total, every pixel's ray count and every sum
+    against the oracle (3 s on the box's 16 host threads; the larger frames are compared whole by tests/fullframe_parity.py, by hand:
+    profiles/r3/fullframe_parity.txt)."""
+    scene, params, camera, sampler = setup(rt, gpu, "C1")
+    oracle_window(rt, gpu, scene, params, camera, sampler, (0, 0, params.image_width, params.image_height))
+
+
 def test_c2_cornell_full_frame(rt, gpu):
     scene, params, camera, sampler = setup(rt, gpu, "C2")
     assert (params.image_width, params.image_height, sampler.spp) == (600, 600, 1000)
