@@ -129,6 +129,14 @@ def test_c2_cornell_full_frame(rt, gpu):
     assert win[380:412, 280:312, 3].min() == 100
 
 
+def test_c2_cornell_whole_frame_at_full_spp_against_the_oracle(rt, gpu):
+    """BASELINE configs[1] as configured, whole: 600 x 600 x 1000 spp, 1.99 G rays — ray total, every pixel's ray count, the NaN
+    pixels and every sum against the oracle (16 s on the box's 16 host threads: a Cornell ray costs the oracle 13 objects)."""
+    scene, params, camera, sampler = setup(rt, gpu, "C2")
+    assert (params.image_width, params.image_height, sampler.spp) == (600, 600, 1000)
+    oracle_window(rt, gpu, scene, params, camera, sampler, (0, 0, 600, 600))
+
+
 def test_c3_book2_windows_of_the_full_frame(rt, gpu):
     scene, params, camera, sampler = setup(rt, gpu, "C3")
     assert (params.image_width, params.image_height, sampler.spp) == (800, 800, 10000)
