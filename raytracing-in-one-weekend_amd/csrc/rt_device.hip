@@ -260,12 +260,15 @@ int render_wavefront(rt_ctx *ctx, const RenderArgs &a, const rt_render_params *p
     ctx->sc.noise_coop = (uint32_t)env_size("RT_NOISE_COOP", 32, 0, 64);   // rt_kernels.h coop_turbulence (0: every noise hit by its own lane)
     const size_t shard_q = (size_t)RT_WF_SHARDS * 256;    // pool sizes are multiples of this
     const size_t need_samples = spp_batch_max * per_sample;
-    // Pipelines: two, or three for a call with a lot to do on a scene whose tree is small (or absent).  Measured with three
-    // against two (profiles/r3/ab_pipelines_3.txt): Book-2 +3 ... +6 %, the Cornell box at 1000 spp +4 %, GeometricPrimitives and
-    // the smoke Cornell box +4 %, Blocks +2 %, Book-1 at 100 spp +1 % — but Book-1 at 10 spp -8 % (a frame of a few milliseconds
-    // is three tails instead of two) and the 2.26 M-triangle mesh -3 ... -6.5 % (three walks at once over a 170 MB tree)
-    const bool many_items = need_samples >= ((size_t)1 << 25), modest_tree = ctx->n_bvh_nodes < (1u << 17);
-    int n_pipes = (int)env_size("RT_WF_PIPES", many_items && modest_tree ? 3 : 2, 1, kMaxPipes);
+    // Pipelines: two, or three for a batch with enough items — how many is enough depends on what the third pipeline has to share
+    // (profiles/r3/ab_pipelines_3.txt, the rounds at its end): without a tree (the Cornell box, Blocks, the small scenes) three win from
+    // 2^25 items on (+6 ... 7.5 %; +1 ... 3 % on the small scenes); with a tree that is held in LDS (Book-1: 234 nodes) from 2^26
+    // (Book-1 at 100 spp +2.3 %, at 1000 spp +4 %, but at 40 spp -3.6 % and at 10 spp -8 %: a short frame is three tails instead
+    // of two); with a larger tree (Book-2: 1 755 nodes) only for the largest batches (+0.5 % at 1000 spp, -2 ... -3 % at 60 - 200 spp);
+    // never on the 2.26 M-triangle mesh (-3 ... -6.5 %: three walks at once over a 170 MB tree).
+    const size_t pipes3_from = !has_bvh ? ((size_t)1 << 25) : ctx->n_bvh_nodes <= 256u ? ((size_t)1 << 26)
+                             : ctx->n_bvh_nodes < (1u << 17) ? ((size_t)1 << 28) : ~(size_t)0;
+    int n_pipes = (int)env_size("RT_WF_PIPES", need_samples >= pipes3_from ? 3 : 2, 1, kMaxPipes);
     if (need_samples < 4 * shard_q || n_tiles < 2u) n_pipes = 1;
     if ((uint32_t)n_pipes > n_tiles) n_pipes = (int)n_tiles;      // every pipeline gets at least one tile (magic_div(tiles_pipe) divides by it)
     // Pool: 2^23 entries over all pipelines — what fits the caches, and the best size for every call of up to a few hundred
